@@ -1,0 +1,143 @@
+/* gsplat_hip.h -- C ABI of the MI355X (gfx950) differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary underneath the three Python calls splat-trainer makes into taichi_splatting
+ * (the reference has no C/FFI layer of its own):
+ *
+ *     project_to_image(gaussians, camera_params, config)            splat_trainer/scene/mlp_scene.py:375,415
+ *     render_projected(indexes, gaussians2d, features, depth, ...)  splat_trainer/scene/mlp_scene.py:377-378,418-419
+ *     evaluate_sh_at(sh_features, positions, indexes, camera_pos)   splat_trainer/scene/transfer_sh.py:49
+ *     loss.backward()  (autograd node of the above)                 splat_trainer/trainer/trainer.py:512
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (torch ``data_ptr()``) unless the name ends in ``_host``;
+ *   - all floating-point data is float32, row-major, contiguous; index tensors at the boundary are int64;
+ *   - nothing here allocates, frees or synchronises: callers pass workspaces sized by the *_workspace_bytes
+ *     queries and a ``hipStream_t`` (as ``void*``; NULL = default stream); calls only enqueue work;
+ *   - camera: ``T_camera_world`` = 16 floats (4x4 row-major world->camera), ``projection`` = fx, fy, cx, cy in
+ *     pixels (splat_trainer/trainer/trainer.py:291-301); both stay on the device, so no host sync is needed;
+ *   - return value: 0 (GSR_OK) or a negative GSR_ERR_* code; the library never throws and never prints;
+ *   - M = 0 and O = 0 are valid inputs everywhere (the reference treats "no visible points" as a caller-level
+ *     error, splat_trainer/trainer/trainer.py:507-509, not a boundary error).
+ *
+ * The maths each entry point implements is specified in oracle/torch_oracle.py (header comment).
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_ERR_INVALID_ARGUMENT -1
+#define GSR_ERR_WORKSPACE_TOO_SMALL -2
+#define GSR_ERR_LAUNCH_FAILED -3
+#define GSR_ERR_UNSUPPORTED -4
+
+#define GSR_REC_FLOATS 12      /* depth-ordered splat record: u v A B | C op depth f0 | f1 f2 - -        */
+#define GSR_PARTIAL_FLOATS 12  /* per-(tile,splat) gradient partial: du dv dA dB | dC dop prune split | df0 df1 df2 - */
+
+#ifndef GSR_HAVE_RASTER_PARAMS
+#define GSR_HAVE_RASTER_PARAMS
+/* Mirrors the RasterConfig fields the reference sets (trainer.py:305-310) plus this build's constants. */
+typedef struct GsrRasterParamsC {
+  float alpha_threshold;  /* 1/255 */
+  float clamp_max_alpha;  /* 0.99 */
+  float T_eps;            /* 1 - saturate_threshold (1e-4) */
+  float q_max;            /* gaussian_scale^2 (9) */
+  float blur;             /* blur_cov (+ aa_blur when antialias) */
+  int32_t antialias;      /* 0 / 1 */
+  int32_t tile_size;      /* must be 16 */
+  float margin_px;        /* margin_tiles * tile_size */
+} GsrRasterParamsC;
+#endif
+
+int gsr_abi_version(void);                 /* bumped on any signature change */
+const char* gsr_error_string(int code);
+
+/* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
+size_t gsr_scan_workspace_bytes(int64_t n);
+int gsr_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_dev, void* workspace,
+                           size_t workspace_bytes, void* stream);
+size_t gsr_sort_workspace_bytes(int64_t n);
+/* Stable LSD radix sort of (key, value) pairs by key bits [begin_bit, end_bit); ping-pongs a<->b.
+ * Returns 0 if the result ends in (keys_a, vals_a), 1 if in (keys_b, vals_b), negative on error. */
+int gsr_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
+                       int vals_are_iota, int begin_bit, int end_bit, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- K1 frustum cull + compaction  (project_to_image, first half) --------------------------------------- */
+size_t gsr_cull_workspace_bytes(int64_t N);
+/* indexes_out: int64[N] capacity, ascending point order; count_dev: uint32 = M. */
+int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_world, const float* projection,
+                     int32_t W, int32_t H, float near_plane, float far_plane, float margin_px,
+                     int64_t* indexes_out, uint32_t* count_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K2 3D->2D projection forward / backward  (project_to_image, second half) --------------------------- */
+/* gaussians2d_out: [M,6] = u v A B C opacity; depth_out: [M]. */
+int gsr_project_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                        const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
+                        const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
+                        float* depth_out, void* stream);
+/* Writes rows ``indexes`` of the N-sized gradient tensors (rows not listed are left untouched: pass zeros). */
+int gsr_project_backward(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
+                         const float* projection, const GsrRasterParamsC* params_host, const float* dL_dgaussians2d,
+                         const float* dL_ddepth, float* d_position, float* d_log_scaling, float* d_rotation,
+                         float* d_alpha_logit, void* stream);
+
+/* ---- K3 spherical-harmonics colour forward / backward  (evaluate_sh_at) --------------------------------- */
+/* sh_features [N,3,K], K in {1,4,9,16}; colour = 0.5 + sum_k sh[c][k] Y_k(normalize(p - camera_pos)). */
+int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
+                   const float* camera_pos, float* colors_out, void* stream);
+int gsr_sh_backward(const float* dL_dcolors, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
+                    const float* camera_pos, float* d_sh_features, void* stream);
+
+/* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */
+/* depth -> sortable u32 keys */
+int gsr_depth_keys(const float* depth, int64_t M, uint32_t* keys_out, void* stream);
+/* For rank k in depth order (order[k] = splat): writes the 12-float record rec[k] and the number of tiles its
+ * support touches; also screen_scale_out[splat] = (sigma_major, sigma_minor) in pixels (sqrt of the eigenvalues
+ * of the blurred 2D covariance).  features: [M,C], C in {1,2,3}. */
+int gsr_tile_count(const float* gaussians2d, const float* depth, const float* features, const uint32_t* order,
+                   int64_t M, int32_t C, int32_t W, int32_t H, const GsrRasterParamsC* params_host, float* rec_out,
+                   uint32_t* count_out, float* screen_scale_out, void* stream);
+/* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id, inst2rank[...] = k. */
+int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
+                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, void* stream);
+/* From tile-sorted (keys, instance ids): per-tile [start, end) and the rank of every sorted instance.
+ * tile_range must be zero-filled by the caller: [num_tiles, 2] uint32. */
+int gsr_tile_ranges(const uint32_t* sorted_keys, const uint32_t* sorted_inst, const uint32_t* inst2rank, int64_t O,
+                    int32_t num_tiles, uint32_t* tile_range, uint32_t* sorted_rank_out, void* stream);
+
+/* ---- K6 alpha-composite forward ------------------------------------------------------------------------- */
+/* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;
+ * median_depth [H,W] or NULL; vis_partial [O] (per sorted instance id) or NULL -- must be zero-filled. */
+int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
+                          const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
+                          const GsrRasterParamsC* params_host, float* image_out, float* final_T_out,
+                          int32_t* last_out, float* median_depth_out, float* vis_partial_out, void* stream);
+
+/* ---- K7 alpha-composite backward (per-pixel reverse walk) ----------------------------------------------- */
+/* partial_out [O,12]: written only for instances with vis_partial > 0 (the others are never read). */
+int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
+                           const float* vis_partial, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
+                           const GsrRasterParamsC* params_host, const float* final_T, const int32_t* last,
+                           const float* dL_dimage, float* partial_out, void* stream);
+
+/* ---- deterministic per-splat reductions of the per-(tile,splat) partials -------------------------------- */
+/* visibility_out [M] indexed by splat (not rank). */
+int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
+                          const uint32_t* order, int64_t M, float* visibility_out, void* stream);
+/* d_gaussians2d [M,6], d_features [M,C], prune_cost [M], split_score [M], indexed by splat. */
+int gsr_reduce_gradients(const float* partial, const float* vis_partial, const uint32_t* offsets,
+                         const uint32_t* count, const uint32_t* order, int64_t M, int32_t C, float* d_gaussians2d,
+                         float* d_features, float* prune_cost_out, float* split_score_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */

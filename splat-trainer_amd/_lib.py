@@ -1,0 +1,97 @@
+"""ctypes binding of the C ABI in include/gsplat_hip.h.
+
+There is no CPU fallback: if ``libgsplat_hip.so`` is missing or fails to load, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
+
+ABI_VERSION = 1
+
+
+class GsrRasterParamsC(C.Structure):
+  _fields_ = [("alpha_threshold", C.c_float), ("clamp_max_alpha", C.c_float), ("T_eps", C.c_float),
+              ("q_max", C.c_float), ("blur", C.c_float), ("antialias", C.c_int32), ("tile_size", C.c_int32),
+              ("margin_px", C.c_float)]
+
+
+def raster_params(config) -> GsrRasterParamsC:
+  blur = float(config.blur_cov) + (float(config.aa_blur) if config.antialias else 0.0)
+  return GsrRasterParamsC(float(config.alpha_threshold), float(config.clamp_max_alpha),
+                          float(config.transmittance_eps), float(config.gaussian_scale) ** 2, blur,
+                          1 if config.antialias else 0, int(config.tile_size),
+                          float(config.margin_tiles * config.tile_size))
+
+
+_p = C.c_void_p
+_i64, _i32, _f, _sz = C.c_int64, C.c_int32, C.c_float, C.c_size_t
+_pp = C.POINTER(GsrRasterParamsC)
+
+# name -> (restype, argtypes); every symbol declared in include/gsplat_hip.h
+PROTOTYPES = {
+    "gsr_abi_version": (C.c_int, []),
+    "gsr_error_string": (C.c_char_p, [C.c_int]),
+    "gsr_scan_workspace_bytes": (_sz, [_i64]),
+    "gsr_exclusive_scan_u32": (C.c_int, [_p, _p, _i64, _p, _p, _sz, _p]),
+    "gsr_sort_workspace_bytes": (_sz, [_i64]),
+    "gsr_sort_pairs_u32": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p]),
+    "gsr_cull_workspace_bytes": (_sz, [_i64]),
+    "gsr_frustum_cull": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _sz, _p]),
+    "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p]),
+    "gsr_project_backward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _p]),
+    "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "gsr_sh_backward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "gsr_depth_keys": (C.c_int, [_p, _i64, _p, _p]),
+    "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p]),
+    "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),
+    "gsr_tile_ranges": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p]),
+    "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p]),
+    "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p]),
+    "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GsplatHipError(RuntimeError):
+  pass
+
+
+def load() -> C.CDLL:
+  """Loads (once) and returns the HIP library; raises GsplatHipError when it is absent."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  with _lock:
+    if _lib is not None:
+      return _lib
+    if not os.path.exists(LIB_PATH):
+      raise GsplatHipError(
+          f"{LIB_PATH} not found: build it with `python splat-trainer_amd/build.py` "
+          "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rasterizer path.")
+    try:
+      lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+      raise GsplatHipError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in PROTOTYPES.items():
+      fn = getattr(lib, name)
+      fn.restype = restype
+      fn.argtypes = argtypes
+    if lib.gsr_abi_version() != ABI_VERSION:
+      raise GsplatHipError(f"ABI mismatch: library {lib.gsr_abi_version()} != binding {ABI_VERSION}; rebuild")
+    _lib = lib
+  return _lib
+
+
+def check(code: int, what: str) -> int:
+  if code < 0:
+    msg = load().gsr_error_string(code).decode()
+    raise GsplatHipError(f"{what} failed: {msg} ({code})")
+  return code

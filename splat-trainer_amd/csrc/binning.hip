@@ -1,0 +1,235 @@
+// K4 tile overlap count + key emit, tile ranges, and the deterministic per-splat reductions of the
+// per-(tile,splat) partials written by the composite kernels.
+//
+// Splats are visited in DEPTH ORDER (rank k -> splat order[k]); instances are emitted rank-major, so the
+// instance stream is already depth-sorted and only a stable sort on the tile id is needed afterwards.
+// The per-tile test is exact for the ellipse {d^T conic d <= qmax} against the tile's rectangle of pixel
+// centres, with qmax shrunk for faint splats (alpha can only reach 1/255 inside 2 ln(255 opacity)).
+#include "gsr_device.h"
+#include "../../include/gsplat_hip.h"
+
+namespace {
+
+inline GsrRasterParams to_params(const GsrRasterParamsC* c) {
+  GsrRasterParams rp;
+  __builtin_memcpy(&rp, c, sizeof(rp));
+  return rp;
+}
+inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+__global__ __launch_bounds__(256) void depth_keys_kernel(const float* __restrict__ depth, int64_t M,
+                                                         uint32_t* __restrict__ keys) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  // depth > near > 0 after the cull, so the IEEE bit pattern is monotone; guard the sign anyway
+  uint32_t b = __float_as_uint(depth[m]);
+  keys[m] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ uint32_t count_tiles(float u, float v, float A, float B, float C, const GsrExtent& e) {
+  uint32_t n = 0;
+  const int nx = e.x1 - e.x0, ny = e.y1 - e.y0;
+  if (nx <= 0 || ny <= 0) return 0;
+  if (nx == 1 && ny == 1) return gsr_tile_hit(u, v, A, B, C, e.qmax, e.x0, e.y0) ? 1u : 0u;
+  for (int ty = e.y0; ty < e.y1; ++ty)
+    for (int tx = e.x0; tx < e.x1; ++tx) n += gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty) ? 1u : 0u;
+  return n;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict__ g2d, const float* __restrict__ depth,
+                                                         const float* __restrict__ feat,
+                                                         const uint32_t* __restrict__ order, int64_t M, int tiles_x,
+                                                         int tiles_y, GsrRasterParams rp, float* __restrict__ rec,
+                                                         uint32_t* __restrict__ count, float* __restrict__ sscale) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const int64_t s = order[k];
+  const float* g = g2d + 6 * s;
+  const float2 uv = *reinterpret_cast<const float2*>(g);
+  const float2 ab = *reinterpret_cast<const float2*>(g + 2);
+  const float2 co = *reinterpret_cast<const float2*>(g + 4);
+  float f0 = feat[C * s], f1 = 0.f, f2 = 0.f;
+  if (C > 1) f1 = feat[C * s + 1];
+  if (C > 2) f2 = feat[C * s + 2];
+  float4* r = reinterpret_cast<float4*>(rec + GSR_REC_FLOATS * k);
+  r[0] = make_float4(uv.x, uv.y, ab.x, ab.y);
+  r[1] = make_float4(co.x, co.y, depth[s], f0);
+  r[2] = make_float4(f1, f2, 0.f, 0.f);
+  GsrExtent e = gsr_splat_extent(uv.x, uv.y, ab.x, ab.y, co.x, co.y, rp, tiles_x, tiles_y);
+  count[k] = count_tiles(uv.x, uv.y, ab.x, ab.y, co.x, e);
+  // sigma = sqrt(eig(cov)), cov = conic^-1 = [C -B; -B A] / det(conic)
+  const float idet = 1.f / (ab.x * co.x - ab.y * ab.y);
+  const float mid = 0.5f * (ab.x + co.x) * idet;
+  const float rad = sqrtf(fmaxf(mid * mid - idet, 0.f));
+  *reinterpret_cast<float2*>(sscale + 2 * s) = make_float2(sqrtf(mid + rad), sqrtf(fmaxf(mid - rad, 0.f)));
+}
+
+__global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict__ rec,
+                                                        const uint32_t* __restrict__ offsets, int64_t M, int tiles_x,
+                                                        int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ inst2rank) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const float4* r = reinterpret_cast<const float4*>(rec + GSR_REC_FLOATS * k);
+  const float4 r0 = r[0];
+  const float4 r1 = r[1];
+  const float u = r0.x, v = r0.y, A = r0.z, B = r0.w, C = r1.x, op = r1.y;
+  GsrExtent e = gsr_splat_extent(u, v, A, B, C, op, rp, tiles_x, tiles_y);
+  uint32_t o = offsets[k];
+  for (int ty = e.y0; ty < e.y1; ++ty)
+    for (int tx = e.x0; tx < e.x1; ++tx)
+      if (gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty)) {
+        keys[o] = (uint32_t)(ty * tiles_x + tx);
+        inst2rank[o] = (uint32_t)k;
+        ++o;
+      }
+}
+
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ inst,
+                                                          const uint32_t* __restrict__ inst2rank, int64_t O,
+                                                          uint32_t* __restrict__ range, uint32_t* __restrict__ rank_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O) return;
+  const uint32_t t = keys[i];
+  if (i == 0 || keys[i - 1] != t) range[2 * t] = (uint32_t)i;
+  if (i == O - 1 || keys[i + 1] != t) range[2 * t + 1] = (uint32_t)(i + 1);
+  rank_out[i] = inst2rank[inst[i]];
+}
+
+// Instances of rank k occupy the contiguous pre-sort ids [offsets[k], offsets[k] + count[k]); summing them in id
+// order gives a fixed association order -> bit-reproducible results (no float atomics anywhere on this path).
+__global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict__ vis_partial,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ count,
+                                                         const uint32_t* __restrict__ order, int64_t M,
+                                                         float* __restrict__ vis) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const uint32_t b = offsets[k], n = count[k];
+  float acc = 0.f;
+  for (uint32_t j = 0; j < n; ++j) acc += vis_partial[b + j];
+  vis[order[k]] = acc;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restrict__ partial,
+                                                          const float* __restrict__ vis_partial,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ count,
+                                                          const uint32_t* __restrict__ order, int64_t M,
+                                                          float* __restrict__ dg2d, float* __restrict__ dfeat,
+                                                          float* __restrict__ prune, float* __restrict__ split) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const uint32_t b = offsets[k], n = count[k];
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+  for (uint32_t j = 0; j < n; ++j) {
+    if (vis_partial[b + j] > 0.f) {          // untouched (tile,splat) pairs were never written
+      const float4* p = reinterpret_cast<const float4*>(partial + (size_t)GSR_PARTIAL_FLOATS * (b + j));
+      const float4 p0 = p[0], p1 = p[1], p2 = p[2];
+      a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+      a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+      a2.x += p2.x; a2.y += p2.y; a2.z += p2.z;
+    }
+  }
+  const int64_t s = order[k];
+  float* g = dg2d + 6 * s;
+  *reinterpret_cast<float2*>(g) = make_float2(a0.x, a0.y);
+  *reinterpret_cast<float2*>(g + 2) = make_float2(a0.z, a0.w);
+  *reinterpret_cast<float2*>(g + 4) = make_float2(a1.x, a1.y);
+  prune[s] = a1.z;
+  split[s] = a1.w;
+  dfeat[C * s] = a2.x;
+  if (C > 1) dfeat[C * s + 1] = a2.y;
+  if (C > 2) dfeat[C * s + 2] = a2.z;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_depth_keys(const float* depth, int64_t M, uint32_t* keys_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!depth || !keys_out) return GSR_ERR_INVALID_ARGUMENT;
+  depth_keys_kernel<<<grid_for(M, 256), 256, 0, stream>>>(depth, M, keys_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_tile_count(const float* gaussians2d, const float* depth, const float* features, const uint32_t* order,
+                   int64_t M, int32_t C, int32_t W, int32_t H, const GsrRasterParamsC* params_host, float* rec_out,
+                   uint32_t* count_out, float* screen_scale_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (params_host->tile_size != 16 || C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
+  if (M == 0) return GSR_OK;
+  if (!gaussians2d || !depth || !features || !order || !rec_out || !count_out || !screen_scale_out) return GSR_ERR_INVALID_ARGUMENT;
+  const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  const GsrRasterParams rp = to_params(params_host);
+  const unsigned g = grid_for(M, 256);
+  if (C == 1) tile_count_kernel<1><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out);
+  else if (C == 2) tile_count_kernel<2><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out);
+  else tile_count_kernel<3><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
+                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
+  if (M == 0) return GSR_OK;
+  if (!rec || !offsets || !keys_out || !inst2rank_out) return GSR_ERR_INVALID_ARGUMENT;
+  const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  tile_emit_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rec, offsets, M, tx, ty, to_params(params_host), keys_out,
+                                                        inst2rank_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_tile_ranges(const uint32_t* sorted_keys, const uint32_t* sorted_inst, const uint32_t* inst2rank, int64_t O,
+                    int32_t num_tiles, uint32_t* tile_range, uint32_t* sorted_rank_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (O < 0 || num_tiles <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (O == 0) return GSR_OK;
+  if (!sorted_keys || !sorted_inst || !inst2rank || !tile_range || !sorted_rank_out) return GSR_ERR_INVALID_ARGUMENT;
+  tile_ranges_kernel<<<grid_for(O, 256), 256, 0, stream>>>(sorted_keys, sorted_inst, inst2rank, O, tile_range,
+                                                          sorted_rank_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
+                          const uint32_t* order, int64_t M, float* visibility_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!offsets || !count || !order || !visibility_out) return GSR_ERR_INVALID_ARGUMENT;
+  reduce_vis_kernel<<<grid_for(M, 256), 256, 0, stream>>>(vis_partial, offsets, count, order, M, visibility_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_reduce_gradients(const float* partial, const float* vis_partial, const uint32_t* offsets,
+                         const uint32_t* count, const uint32_t* order, int64_t M, int32_t C, float* d_gaussians2d,
+                         float* d_features, float* prune_cost_out, float* split_score_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
+  if (M == 0) return GSR_OK;
+  if (!offsets || !count || !order || !d_gaussians2d || !d_features || !prune_cost_out || !split_score_out)
+    return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(M, 256);
+  if (C == 1) reduce_grad_kernel<1><<<g, 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, d_gaussians2d, d_features, prune_cost_out, split_score_out);
+  else if (C == 2) reduce_grad_kernel<2><<<g, 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, d_gaussians2d, d_features, prune_cost_out, split_score_out);
+  else reduce_grad_kernel<3><<<g, 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, d_gaussians2d, d_features, prune_cost_out, split_score_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+// K1 frustum cull + wave-ballot compaction, K2 3D->2D projection fwd/bwd, K3 SH colour fwd/bwd.
+// All HBM-streaming kernels: one thread per point, coalesced row reads, no LDS.
+#include "gsr_device.h"
+#include "../../include/gsplat_hip.h"
+
+static_assert(sizeof(GsrRasterParams) == sizeof(GsrRasterParamsC), "raster params layout");
+
+namespace {
+
+constexpr int CULL_ITEMS = 16;                     // points per lane
+constexpr int CULL_WAVE_SPAN = 64 * CULL_ITEMS;    // 1024 consecutive points per wave
+
+// pass 1: each wave counts the in-view points of its 1024-point span (ballot + popcount)
+__global__ __launch_bounds__(256) void cull_count_kernel(const float* __restrict__ pos, int64_t N,
+                                                         const float* __restrict__ Tcw, const float* __restrict__ proj,
+                                                         int W, int H, float near_p, float far_p, float margin,
+                                                         uint32_t* __restrict__ wave_counts, int64_t num_waves) {
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= num_waves) return;
+  const int lane = gsr_lane();
+  const GsrCam cam = gsr_load_cam(Tcw, proj);
+  const int64_t base = wave * CULL_WAVE_SPAN;
+  uint32_t cnt = 0;
+#pragma unroll 4
+  for (int it = 0; it < CULL_ITEMS; ++it) {
+    int64_t i = base + it * 64 + lane;
+    bool in = false;
+    if (i < N) in = gsr_in_view(cam, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], W, H, near_p, far_p, margin);
+    cnt += (uint32_t)__popcll(__ballot(in));
+  }
+  if (lane == 0) wave_counts[wave] = cnt;
+}
+
+// pass 2: recompute the flags, rank by mbcnt below the lane, write indices in ascending point order
+__global__ __launch_bounds__(256) void cull_write_kernel(const float* __restrict__ pos, int64_t N,
+                                                         const float* __restrict__ Tcw, const float* __restrict__ proj,
+                                                         int W, int H, float near_p, float far_p, float margin,
+                                                         const uint32_t* __restrict__ wave_offsets, int64_t num_waves,
+                                                         int64_t* __restrict__ indexes) {
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= num_waves) return;
+  const int lane = gsr_lane();
+  const GsrCam cam = gsr_load_cam(Tcw, proj);
+  const int64_t base = wave * CULL_WAVE_SPAN;
+  uint32_t run = wave_offsets[wave];
+#pragma unroll 4
+  for (int it = 0; it < CULL_ITEMS; ++it) {
+    int64_t i = base + it * 64 + lane;
+    bool in = false;
+    if (i < N) in = gsr_in_view(cam, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], W, H, near_p, far_p, margin);
+    uint64_t m = __ballot(in);
+    if (in) indexes[run + (uint32_t)gsr_mbcnt(m)] = i;
+    run += (uint32_t)__popcll(m);
+  }
+}
+
+__global__ __launch_bounds__(256) void project_fwd_kernel(const float* __restrict__ pos, const float* __restrict__ ls,
+                                                          const float* __restrict__ rot, const float* __restrict__ logit,
+                                                          const int64_t* __restrict__ idx, int64_t M,
+                                                          const float* __restrict__ Tcw, const float* __restrict__ proj,
+                                                          GsrRasterParams rp, float* __restrict__ g2d,
+                                                          float* __restrict__ depth) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const GsrCam cam = gsr_load_cam(Tcw, proj);
+  const int64_t i = idx[m];
+  float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  float s[3] = {ls[3 * i], ls[3 * i + 1], ls[3 * i + 2]};
+  const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * i);
+  float q[4] = {qv.x, qv.y, qv.z, qv.w};
+  GsrProjected o = gsr_project_one(cam, rp, p, s, q, logit[i]);
+  float* g = g2d + 6 * m;
+  *reinterpret_cast<float2*>(g) = make_float2(o.u, o.v);
+  *reinterpret_cast<float2*>(g + 2) = make_float2(o.A, o.B);
+  *reinterpret_cast<float2*>(g + 4) = make_float2(o.C, o.opacity);
+  depth[m] = o.depth;
+}
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ ls,
+                                                          const float* __restrict__ rot, const float* __restrict__ logit,
+                                                          const int64_t* __restrict__ idx, int64_t M,
+                                                          const float* __restrict__ Tcw, const float* __restrict__ proj,
+                                                          GsrRasterParams rp, const float* __restrict__ dg2d,
+                                                          const float* __restrict__ ddepth, float* __restrict__ dpos,
+                                                          float* __restrict__ dls, float* __restrict__ drot,
+                                                          float* __restrict__ dlogit) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const GsrCam cam = gsr_load_cam(Tcw, proj);
+  const int64_t i = idx[m];
+  float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  float s[3] = {ls[3 * i], ls[3 * i + 1], ls[3 * i + 2]};
+  const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * i);
+  float q[4] = {qv.x, qv.y, qv.z, qv.w};
+  float g[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) g[k] = dg2d[6 * m + k];
+  const float gd = ddepth ? ddepth[m] : 0.f;
+  GsrProjectGrad o = gsr_project_one_bwd(cam, rp, p, s, q, logit[i], g, gd);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    dpos[3 * i + k] = o.dp[k];
+    dls[3 * i + k] = o.dls[k];
+  }
+  *reinterpret_cast<float4*>(drot + 4 * i) = make_float4(o.dq[0], o.dq[1], o.dq[2], o.dq[3]);
+  dlogit[i] = o.dlogit;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ sh, const float* __restrict__ pos,
+                                                     const int64_t* __restrict__ idx, int64_t M,
+                                                     const float* __restrict__ cam_pos, float* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int64_t i = idx[m];
+  float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
+  float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+  float Y[K];
+  gsr_sh_basis<K>(dx * inv, dy * inv, dz * inv, Y);
+  const float* row = sh + (int64_t)3 * K * i;
+  float c[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float acc = 0.5f;
+    if (K % 4 == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k += 4) {
+        float4 v = *reinterpret_cast<const float4*>(row + ch * K + k);
+        acc += v.x * Y[k] + v.y * Y[k + 1] + v.z * Y[k + 2] + v.w * Y[k + 3];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc += row[ch * K + k] * Y[k];
+    }
+    c[ch] = acc;
+  }
+  out[3 * m] = c[0]; out[3 * m + 1] = c[1]; out[3 * m + 2] = c[2];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ dcol, const float* __restrict__ pos,
+                                                     const int64_t* __restrict__ idx, int64_t M,
+                                                     const float* __restrict__ cam_pos, float* __restrict__ dsh) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int64_t i = idx[m];
+  float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
+  float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+  float Y[K];
+  gsr_sh_basis<K>(dx * inv, dy * inv, dz * inv, Y);
+  float* row = dsh + (int64_t)3 * K * i;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float g = dcol[3 * m + ch];
+    if (K % 4 == 0) {
+#pragma unroll
+      for (int k = 0; k < K; k += 4)
+        *reinterpret_cast<float4*>(row + ch * K + k) = make_float4(g * Y[k], g * Y[k + 1], g * Y[k + 2], g * Y[k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) row[ch * K + k] = g * Y[k];
+    }
+  }
+}
+
+inline GsrRasterParams to_params(const GsrRasterParamsC* c) {
+  GsrRasterParams rp;
+  __builtin_memcpy(&rp, c, sizeof(rp));
+  return rp;
+}
+
+inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return 1; }
+
+const char* gsr_error_string(int code) {
+  switch (code) {
+    case GSR_OK: return "ok";
+    case GSR_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case GSR_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+    case GSR_ERR_LAUNCH_FAILED: return "kernel launch failed";
+    case GSR_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+
+size_t gsr_cull_workspace_bytes(int64_t N) {
+  if (N < 0) N = 0;
+  int64_t nw = (N + CULL_WAVE_SPAN - 1) / CULL_WAVE_SPAN;
+  size_t counts = (((size_t)nw * sizeof(uint32_t) + 255) / 256) * 256;
+  return counts + gsr_scan_workspace_bytes(nw) + 256;
+}
+
+int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_world, const float* projection, int32_t W,
+                     int32_t H, float near_plane, float far_plane, float margin_px, int64_t* indexes_out,
+                     uint32_t* count_dev, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || N > 0x7FFFFFFFll || !count_dev || !T_camera_world || !projection) return GSR_ERR_INVALID_ARGUMENT;
+  if (N == 0) { hipMemsetAsync(count_dev, 0, sizeof(uint32_t), stream); return GSR_OK; }
+  if (!position || !indexes_out) return GSR_ERR_INVALID_ARGUMENT;
+  if (!workspace || workspace_bytes < gsr_cull_workspace_bytes(N)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  const int64_t nw = (N + CULL_WAVE_SPAN - 1) / CULL_WAVE_SPAN;
+  uint32_t* wave_counts = reinterpret_cast<uint32_t*>(workspace);
+  size_t counts_bytes = (((size_t)nw * sizeof(uint32_t) + 255) / 256) * 256;
+  uint8_t* scan_ws = reinterpret_cast<uint8_t*>(workspace) + counts_bytes;
+  const unsigned blocks = grid_for(nw, 4);
+  cull_count_kernel<<<blocks, 256, 0, stream>>>(position, N, T_camera_world, projection, W, H, near_plane, far_plane,
+                                               margin_px, wave_counts, nw);
+  GSR_CHECK_LAUNCH();
+  int rc = gsr_exclusive_scan_u32(wave_counts, wave_counts, nw, count_dev, scan_ws, workspace_bytes - counts_bytes, stream_);
+  if (rc != GSR_OK) return rc;
+  cull_write_kernel<<<blocks, 256, 0, stream>>>(position, N, T_camera_world, projection, W, H, near_plane, far_plane,
+                                               margin_px, wave_counts, nw, indexes_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_project_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                        const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
+                        const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
+                        float* depth_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!position || !log_scaling || !rotation_xyzw || !alpha_logit || !indexes || !T_camera_world || !projection ||
+      !gaussians2d_out || !depth_out)
+    return GSR_ERR_INVALID_ARGUMENT;
+  project_fwd_kernel<<<grid_for(M, 256), 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
+                                                          T_camera_world, projection, to_params(params_host),
+                                                          gaussians2d_out, depth_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_project_backward(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
+                         const float* projection, const GsrRasterParamsC* params_host, const float* dL_dgaussians2d,
+                         const float* dL_ddepth, float* d_position, float* d_log_scaling, float* d_rotation,
+                         float* d_alpha_logit, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!position || !log_scaling || !rotation_xyzw || !alpha_logit || !indexes || !T_camera_world || !projection ||
+      !dL_dgaussians2d || !d_position || !d_log_scaling || !d_rotation || !d_alpha_logit)
+    return GSR_ERR_INVALID_ARGUMENT;
+  project_bwd_kernel<<<grid_for(M, 256), 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
+                                                          T_camera_world, projection, to_params(params_host),
+                                                          dL_dgaussians2d, dL_ddepth, d_position, d_log_scaling,
+                                                          d_rotation, d_alpha_logit);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
+                   const float* camera_pos, float* colors_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
+  if (M == 0) return GSR_OK;
+  if (!sh_features || !positions || !indexes || !camera_pos || !colors_out) return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(M, 256);
+  switch (K) {
+    case 1: sh_fwd_kernel<1><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
+    case 4: sh_fwd_kernel<4><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
+    case 9: sh_fwd_kernel<9><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
+    default: sh_fwd_kernel<16><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
+  }
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_sh_backward(const float* dL_dcolors, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
+                    const float* camera_pos, float* d_sh_features, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
+  if (M == 0) return GSR_OK;
+  if (!dL_dcolors || !positions || !indexes || !camera_pos || !d_sh_features) return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(M, 256);
+  switch (K) {
+    case 1: sh_bwd_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
+    case 4: sh_bwd_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
+    case 9: sh_bwd_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
+    default: sh_bwd_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
+  }
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+// Per-splat maths shared by the HIP kernels (device) and the CPU unit-test shim (host).
+// Pure functions, no memory access, no wave intrinsics.  Spec: oracle/torch_oracle.py header.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define GSR_HD __host__ __device__ __forceinline__
+#else
+#define GSR_HD inline
+#endif
+
+struct GsrRasterParams {
+  float alpha_threshold;   // 1/255
+  float clamp_max_alpha;   // 0.99
+  float T_eps;             // 1 - saturate_threshold
+  float q_max;             // gaussian_scale^2
+  float blur;              // blur_cov (+ aa_blur when antialias)
+  int   antialias;         // 0/1
+  int   tile_size;         // 16 (kernels are specialised for 16)
+  float margin_px;         // margin_tiles * tile_size
+};
+
+struct GsrCam {            // loaded from the device-resident T_camera_world (4x4 row major) + projection
+  float R[9];
+  float t[3];
+  float fx, fy, cx, cy;
+};
+
+GSR_HD GsrCam gsr_load_cam(const float* T, const float* proj) {
+  GsrCam c;
+  c.R[0] = T[0]; c.R[1] = T[1]; c.R[2] = T[2];  c.t[0] = T[3];
+  c.R[3] = T[4]; c.R[4] = T[5]; c.R[5] = T[6];  c.t[1] = T[7];
+  c.R[6] = T[8]; c.R[7] = T[9]; c.R[8] = T[10]; c.t[2] = T[11];
+  c.fx = proj[0]; c.fy = proj[1]; c.cx = proj[2]; c.cy = proj[3];
+  return c;
+}
+
+GSR_HD void gsr_to_camera(const GsrCam& c, float px, float py, float pz, float& x, float& y, float& z) {
+  x = c.R[0] * px + c.R[1] * py + c.R[2] * pz + c.t[0];
+  y = c.R[3] * px + c.R[4] * py + c.R[5] * pz + c.t[1];
+  z = c.R[6] * px + c.R[7] * py + c.R[8] * pz + c.t[2];
+}
+
+// centre-in-frustum test (K1).  The expanded image bound keeps x/z, y/z bounded for K2.
+GSR_HD bool gsr_in_view(const GsrCam& c, float px, float py, float pz, int W, int H,
+                        float near_p, float far_p, float margin) {
+  float x, y, z;
+  gsr_to_camera(c, px, py, pz, x, y, z);
+  if (!(z > near_p && z < far_p)) return false;
+  float u = c.fx * x / z + c.cx;
+  float v = c.fy * y / z + c.cy;
+  return (u > -margin) && (u < (float)W + margin) && (v > -margin) && (v < (float)H + margin);
+}
+
+GSR_HD void gsr_quat_to_rot(const float qn[4], float Rq[9]) {   // xyzw, already normalised
+  float x = qn[0], y = qn[1], z = qn[2], w = qn[3];
+  Rq[0] = 1.f - 2.f * (y * y + z * z); Rq[1] = 2.f * (x * y - w * z);       Rq[2] = 2.f * (x * z + w * y);
+  Rq[3] = 2.f * (x * y + w * z);       Rq[4] = 1.f - 2.f * (x * x + z * z); Rq[5] = 2.f * (y * z - w * x);
+  Rq[6] = 2.f * (x * z - w * y);       Rq[7] = 2.f * (y * z + w * x);       Rq[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+struct GsrProjected {
+  float u, v, A, B, C, opacity, depth, s_major, s_minor;
+};
+
+// K2 forward for one splat.
+GSR_HD GsrProjected gsr_project_one(const GsrCam& c, const GsrRasterParams& rp, const float p[3],
+                                    const float ls[3], const float q[4], float logit) {
+  GsrProjected o;
+  float x, y, z;
+  gsr_to_camera(c, p[0], p[1], p[2], x, y, z);
+  float iz = 1.f / z;
+  o.u = c.fx * x * iz + c.cx;
+  o.v = c.fy * y * iz + c.cy;
+  o.depth = z;
+
+  float qn[4];
+  float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) qn[i] = q[i] * inv;
+  float Rq[9];
+  gsr_quat_to_rot(qn, Rq);
+  float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
+
+  // Wm = J * R_cw  (2x3)
+  float j00 = c.fx * iz, j02 = -c.fx * x * iz * iz, j11 = c.fy * iz, j12 = -c.fy * y * iz * iz;
+  float Wm[6];
+  for (int k = 0; k < 3; ++k) {
+    Wm[k]     = j00 * c.R[k]     + j02 * c.R[6 + k];
+    Wm[3 + k] = j11 * c.R[3 + k] + j12 * c.R[6 + k];
+  }
+  // Tm = Wm * (Rq diag(s))  (2x3)
+  float Tm[6];
+  for (int cc = 0; cc < 3; ++cc) {
+    float m0 = Rq[cc] * s[cc], m1 = Rq[3 + cc] * s[cc], m2 = Rq[6 + cc] * s[cc];
+    Tm[cc]     = Wm[0] * m0 + Wm[1] * m1 + Wm[2] * m2;
+    Tm[3 + cc] = Wm[3] * m0 + Wm[4] * m1 + Wm[5] * m2;
+  }
+  float a0 = Tm[0] * Tm[0] + Tm[1] * Tm[1] + Tm[2] * Tm[2];
+  float b0 = Tm[0] * Tm[3] + Tm[1] * Tm[4] + Tm[2] * Tm[5];
+  float c0 = Tm[3] * Tm[3] + Tm[4] * Tm[4] + Tm[5] * Tm[5];
+  float a = a0 + rp.blur, b = b0, cc2 = c0 + rp.blur;
+  float det = a * cc2 - b * b;
+  float idet = 1.f / det;
+  o.A = cc2 * idet; o.B = -b * idet; o.C = a * idet;
+  float op = 1.f / (1.f + expf(-logit));
+  if (rp.antialias) {
+    float rho = (a0 * c0 - b0 * b0) * idet;
+    op *= sqrtf(fmaxf(rho, 0.f));
+  }
+  o.opacity = op;
+  float mid = 0.5f * (a + cc2);
+  float rad = sqrtf(fmaxf(mid * mid - det, 0.f));
+  o.s_major = sqrtf(mid + rad);
+  o.s_minor = sqrtf(fmaxf(mid - rad, 0.f));
+  return o;
+}
+
+struct GsrProjectGrad {
+  float dp[3], dls[3], dq[4], dlogit;
+};
+
+// K2 backward for one splat: g = dL/d[u v A B C opacity], gdepth = dL/ddepth.
+GSR_HD GsrProjectGrad gsr_project_one_bwd(const GsrCam& c, const GsrRasterParams& rp, const float p[3],
+                                          const float ls[3], const float q[4], float logit,
+                                          const float g[6], float gdepth) {
+  GsrProjectGrad o;
+  float x, y, z;
+  gsr_to_camera(c, p[0], p[1], p[2], x, y, z);
+  float iz = 1.f / z, iz2 = iz * iz;
+
+  float qlen2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  float inv = 1.f / sqrtf(qlen2);
+  float qn[4];
+  for (int i = 0; i < 4; ++i) qn[i] = q[i] * inv;
+  float Rq[9];
+  gsr_quat_to_rot(qn, Rq);
+  float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
+
+  float j00 = c.fx * iz, j02 = -c.fx * x * iz2, j11 = c.fy * iz, j12 = -c.fy * y * iz2;
+  float Wm[6];
+  for (int k = 0; k < 3; ++k) {
+    Wm[k]     = j00 * c.R[k]     + j02 * c.R[6 + k];
+    Wm[3 + k] = j11 * c.R[3 + k] + j12 * c.R[6 + k];
+  }
+  float Mw[9];
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc) Mw[3 * r + cc] = Rq[3 * r + cc] * s[cc];
+  float Tm[6];
+  for (int cc = 0; cc < 3; ++cc) {
+    Tm[cc]     = Wm[0] * Mw[cc] + Wm[1] * Mw[3 + cc] + Wm[2] * Mw[6 + cc];
+    Tm[3 + cc] = Wm[3] * Mw[cc] + Wm[4] * Mw[3 + cc] + Wm[5] * Mw[6 + cc];
+  }
+  float a0 = Tm[0] * Tm[0] + Tm[1] * Tm[1] + Tm[2] * Tm[2];
+  float b0 = Tm[0] * Tm[3] + Tm[1] * Tm[4] + Tm[2] * Tm[5];
+  float c0 = Tm[3] * Tm[3] + Tm[4] * Tm[4] + Tm[5] * Tm[5];
+  float a = a0 + rp.blur, b = b0, cc2 = c0 + rp.blur;
+  float det = a * cc2 - b * b;
+  float idet = 1.f / det, idet2 = idet * idet;
+
+  // conic (A,B,C) = (c, -b, a)/det  ->  (a, b, c)
+  float gA = g[2], gB = g[3], gC = g[4];
+  float ga = gA * (-cc2 * cc2 * idet2) + gB * (b * cc2 * idet2)            + gC * (-b * b * idet2);
+  float gb = gA * (2.f * b * cc2 * idet2) + gB * (-(a * cc2 + b * b) * idet2) + gC * (2.f * a * b * idet2);
+  float gc = gA * (-b * b * idet2)     + gB * (a * b * idet2)             + gC * (-a * a * idet2);
+
+  float sig = 1.f / (1.f + expf(-logit));
+  float gsig = g[5];
+  if (rp.antialias) {
+    float det0 = a0 * c0 - b0 * b0;
+    float rho = det0 * idet;
+    if (rho > 0.f) {
+      float r = sqrtf(rho);
+      float g_rho = g[5] * sig / (2.f * r);
+      float g_det0 = g_rho * idet;
+      float g_det = -g_rho * det0 * idet2;
+      ga += g_det0 * c0 + g_det * cc2;
+      gb += -2.f * b0 * g_det0 - 2.f * b * g_det;
+      gc += g_det0 * a0 + g_det * a;
+      gsig = g[5] * r;
+    } else {
+      gsig = 0.f;
+    }
+  }
+  o.dlogit = gsig * sig * (1.f - sig);
+
+  // cov -> Tm
+  float gT[6];
+  for (int cc = 0; cc < 3; ++cc) {
+    gT[cc]     = 2.f * ga * Tm[cc] + gb * Tm[3 + cc];
+    gT[3 + cc] = 2.f * gc * Tm[3 + cc] + gb * Tm[cc];
+  }
+  // Tm = Wm Mw
+  float gW[6], gM[9];
+  for (int k = 0; k < 3; ++k) {
+    gW[k]     = gT[0] * Mw[3 * k] + gT[1] * Mw[3 * k + 1] + gT[2] * Mw[3 * k + 2];
+    gW[3 + k] = gT[3] * Mw[3 * k] + gT[4] * Mw[3 * k + 1] + gT[5] * Mw[3 * k + 2];
+    for (int cc = 0; cc < 3; ++cc) gM[3 * k + cc] = Wm[k] * gT[cc] + Wm[3 + k] * gT[3 + cc];
+  }
+  // Mw = Rq diag(s)
+  float gR[9];
+  for (int cc = 0; cc < 3; ++cc) {
+    float gs = gM[cc] * Rq[cc] + gM[3 + cc] * Rq[3 + cc] + gM[6 + cc] * Rq[6 + cc];
+    o.dls[cc] = gs * s[cc];
+    gR[cc] = gM[cc] * s[cc]; gR[3 + cc] = gM[3 + cc] * s[cc]; gR[6 + cc] = gM[6 + cc] * s[cc];
+  }
+  // rotmat -> unit quaternion (xyzw)
+  {
+    float qx = qn[0], qy = qn[1], qz = qn[2], qw = qn[3];
+    float gx = 2.f * (qy * (gR[1] + gR[3]) + qz * (gR[2] + gR[6]) - 2.f * qx * (gR[4] + gR[8]) + qw * (gR[7] - gR[5]));
+    float gy = 2.f * (qx * (gR[1] + gR[3]) + qz * (gR[5] + gR[7]) - 2.f * qy * (gR[0] + gR[8]) + qw * (gR[2] - gR[6]));
+    float gz = 2.f * (qx * (gR[2] + gR[6]) + qy * (gR[5] + gR[7]) - 2.f * qz * (gR[0] + gR[4]) + qw * (gR[3] - gR[1]));
+    float gw = 2.f * (qz * (gR[3] - gR[1]) + qy * (gR[2] - gR[6]) + qx * (gR[7] - gR[5]));
+    float dot = qx * gx + qy * gy + qz * gz + qw * gw;    // through q / |q|
+    o.dq[0] = (gx - qx * dot) * inv;
+    o.dq[1] = (gy - qy * dot) * inv;
+    o.dq[2] = (gz - qz * dot) * inv;
+    o.dq[3] = (gw - qw * dot) * inv;
+  }
+  // Wm = J R_cw -> J
+  float gJ00 = gW[0] * c.R[0] + gW[1] * c.R[1] + gW[2] * c.R[2];
+  float gJ02 = gW[0] * c.R[6] + gW[1] * c.R[7] + gW[2] * c.R[8];
+  float gJ11 = gW[3] * c.R[3] + gW[4] * c.R[4] + gW[5] * c.R[5];
+  float gJ12 = gW[3] * c.R[6] + gW[4] * c.R[7] + gW[5] * c.R[8];
+  float iz3 = iz2 * iz;
+  float gxc = gJ02 * (-c.fx * iz2) + g[0] * c.fx * iz;
+  float gyc = gJ12 * (-c.fy * iz2) + g[1] * c.fy * iz;
+  float gzc = gJ00 * (-c.fx * iz2) + gJ02 * (2.f * c.fx * x * iz3)
+            + gJ11 * (-c.fy * iz2) + gJ12 * (2.f * c.fy * y * iz3)
+            - g[0] * c.fx * x * iz2 - g[1] * c.fy * y * iz2 + gdepth;
+  o.dp[0] = c.R[0] * gxc + c.R[3] * gyc + c.R[6] * gzc;
+  o.dp[1] = c.R[1] * gxc + c.R[4] * gyc + c.R[7] * gzc;
+  o.dp[2] = c.R[2] * gxc + c.R[5] * gyc + c.R[8] * gzc;
+  return o;
+}
+
+// ------------------------------------------------------------------ SH basis, degrees 0..3
+#define GSR_SH_C0 0.28209479177387814f
+#define GSR_SH_C1 0.4886025119029199f
+
+template <int K>
+GSR_HD void gsr_sh_basis(float x, float y, float z, float* Y) {
+  Y[0] = GSR_SH_C0;
+  if (K > 1) {
+    Y[1] = -GSR_SH_C1 * y; Y[2] = GSR_SH_C1 * z; Y[3] = -GSR_SH_C1 * x;
+  }
+  if (K > 4) {
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    Y[4] = 1.0925484305920792f * xy;
+    Y[5] = -1.0925484305920792f * yz;
+    Y[6] = 0.31539156525252005f * (2.f * zz - xx - yy);
+    Y[7] = -1.0925484305920792f * xz;
+    Y[8] = 0.5462742152960396f * (xx - yy);
+    if (K > 9) {
+      Y[9]  = -0.5900435899266435f * y * (3.f * xx - yy);
+      Y[10] = 2.890611442640554f * xy * z;
+      Y[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+      Y[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+      Y[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+      Y[14] = 1.445305721320277f * z * (xx - yy);
+      Y[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ tile binning maths (K4)
+struct GsrExtent {            // half-open tile rectangle [x0,x1) x [y0,y1) and the effective support
+  int x0, x1, y0, y1;
+  float qmax;                 // d^T conic d <= qmax can reach alpha >= alpha_threshold
+};
+
+// Conservative support of a projected splat: q <= min(q_max, 2 ln(opacity / alpha_threshold)) (inflated a
+// hair so that fp32 rounding in the per-pixel test can never include a pixel the binning excluded).
+GSR_HD GsrExtent gsr_splat_extent(float u, float v, float A, float B, float C, float op,
+                                  const GsrRasterParams& rp, int tiles_x, int tiles_y) {
+  GsrExtent e;
+  e.x0 = e.x1 = e.y0 = e.y1 = 0;
+  e.qmax = 0.f;
+  if (!(op >= rp.alpha_threshold)) return e;
+  float qop = 2.f * logf(op / rp.alpha_threshold) * 1.0001f + 1e-4f;
+  float qmax = fminf(rp.q_max * 1.00001f, qop);
+  float det = A * C - B * B;
+  if (!(det > 0.f)) return e;
+  float hx = sqrtf(qmax * C / det) + 1e-3f;     // cov_xx = C/det, cov_yy = A/det
+  float hy = sqrtf(qmax * A / det) + 1e-3f;
+  const float ts = 16.f;
+  // pixel centres of tile column k span [16k + .5, 16k + 15.5]
+  float fx0 = floorf((u - hx - 0.5f) / ts), fx1 = floorf((u + hx - 0.5f) / ts) + 1.f;
+  float fy0 = floorf((v - hy - 0.5f) / ts), fy1 = floorf((v + hy - 0.5f) / ts) + 1.f;
+  e.x0 = (int)fminf(fmaxf(fx0, 0.f), (float)tiles_x);
+  e.x1 = (int)fminf(fmaxf(fx1, 0.f), (float)tiles_x);
+  e.y0 = (int)fminf(fmaxf(fy0, 0.f), (float)tiles_y);
+  e.y1 = (int)fminf(fmaxf(fy1, 0.f), (float)tiles_y);
+  e.qmax = qmax;
+  return e;
+}
+
+// min over a segment of the quadratic q restricted to a line: fixed offset d_fixed on one axis,
+// free offset in [lo, hi] on the other.  q = Kf d_fixed^2 + 2 B d_fixed d + Kv d^2.
+GSR_HD float gsr_edge_min_q(float Kf, float Bc, float Kv, float d_fixed, float lo, float hi) {
+  float d = -Bc * d_fixed / Kv;
+  d = fminf(fmaxf(d, lo), hi);
+  return Kf * d_fixed * d_fixed + 2.f * Bc * d_fixed * d + Kv * d * d;
+}
+
+// Does the ellipse {q <= qmax} reach the rectangle of pixel centres of tile (tx, ty)?
+GSR_HD bool gsr_tile_hit(float u, float v, float A, float B, float C, float qmax, int tx, int ty) {
+  float rx0 = 16.f * tx + 0.5f - u, rx1 = 16.f * tx + 15.5f - u;   // rectangle relative to the mean
+  float ry0 = 16.f * ty + 0.5f - v, ry1 = 16.f * ty + 15.5f - v;
+  if (rx0 <= 0.f && rx1 >= 0.f && ry0 <= 0.f && ry1 >= 0.f) return true;
+  float m = gsr_edge_min_q(A, B, C, rx0, ry0, ry1);
+  m = fminf(m, gsr_edge_min_q(A, B, C, rx1, ry0, ry1));
+  m = fminf(m, gsr_edge_min_q(C, B, A, ry0, rx0, rx1));
+  m = fminf(m, gsr_edge_min_q(C, B, A, ry1, rx0, rx1));
+  return m <= qmax;
+}

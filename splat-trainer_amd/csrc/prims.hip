@@ -1,0 +1,242 @@
+// Device-wide primitives for the binning stage: exclusive scan (u32) and a stable LSD radix sort of
+// (u32 key, u32 value) pairs over an arbitrary bit range.  Hand-written for wave64; no rocPRIM.
+//
+// K5 of SURVEY.md §2a ("radix sort by (tile, depth) + tile ranges").  The path sorts twice:
+//   (1) the M visible splats by depth bits (32-bit keys, 4 passes)  -> depth order, ties by index (stable)
+//   (2) the O tile instances, emitted in depth order, by tile id (ceil(log2 tiles) bits, 2 passes)
+// so the big array moves through 2 passes instead of the 6 a fused 48-bit (tile|depth) key would need.
+#include "gsr_device.h"
+#include "../../include/gsplat_hip.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // 4096 elements per block
+
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns exclusive prefix,
+// total in *total_out (same for all threads).
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* total_out) {
+  __shared__ uint32_t s_wave[4];
+  const int lane = gsr_lane(), wave = threadIdx.x >> 6;
+  uint32_t incl = gsr_wave_scan_incl_u32(v);
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    uint32_t c = s_wave[w];
+    if (w < wave) base += c;
+    total += c;
+  }
+  __syncthreads();
+  *total_out = total;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n,
+                                                                   uint32_t* __restrict__ block_sums) {
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint32_t idx = base + i;
+    sum += (idx < n) ? in[idx] : 0u;
+  }
+  uint32_t total;
+  block_scan_excl(sum, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// out[i] = block_offsets[b] + exclusive prefix inside the block.  block_offsets may be null (single block).
+// The grand total (sum of everything) is written to *total_out by the last block when total_out != null.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* in, uint32_t n,   // in may alias out
+                                                                  const uint32_t* __restrict__ block_offsets,
+                                                                  uint32_t* out, uint32_t* __restrict__ total_out) {
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint32_t idx = base + i;
+    v[i] = (idx < n) ? in[idx] : 0u;
+    sum += v[i];
+  }
+  uint32_t total;
+  uint32_t excl = block_scan_excl(sum, &total);
+  uint32_t boff = block_offsets ? block_offsets[blockIdx.x] : 0u;
+  uint32_t run = boff + excl;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint32_t idx = base + i;
+    if (idx < n) out[idx] = run;
+    run += v[i];
+  }
+  if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = boff + total;
+}
+
+size_t scan_ws_bytes(uint64_t n) {
+  size_t bytes = 0;
+  while (n > SCAN_TILE) {
+    uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    bytes += ((nb * sizeof(uint32_t) + 255) / 256) * 256;
+    n = nb;
+  }
+  return bytes + 256;
+}
+
+int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, uint8_t* ws, hipStream_t stream) {
+  if (n == 0) {
+    if (total_dev) hipMemsetAsync(total_dev, 0, sizeof(uint32_t), stream);
+    return GSR_OK;
+  }
+  uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+  if (nb == 1) {
+    scan_apply_kernel<<<1, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, nullptr, out, total_dev);
+    GSR_CHECK_LAUNCH();
+    return GSR_OK;
+  }
+  uint32_t* block_sums = reinterpret_cast<uint32_t*>(ws);
+  size_t used = (((size_t)nb * sizeof(uint32_t) + 255) / 256) * 256;
+  scan_reduce_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums);
+  GSR_CHECK_LAUNCH();
+  int rc = scan_impl(block_sums, block_sums, nb, nullptr, ws + used, stream);   // in place
+  if (rc != GSR_OK) return rc;
+  scan_apply_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, out, total_dev);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ radix sort
+constexpr int RS_THREADS = 256;
+constexpr int RS_ROUNDS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;   // 4096 pairs per block
+constexpr int RS_BINS = 256;
+
+// per-block digit histogram, stored digit-major: hist[digit * num_blocks + block]
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                             uint32_t mask, uint32_t* __restrict__ hist,
+                                                             uint32_t num_blocks) {
+  __shared__ uint32_t s_hist[RS_BINS];
+  s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    uint32_t idx = base + r * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  hist[threadIdx.x * num_blocks + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// stable scatter: elements keep their input order inside every digit bucket.
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in,   // null -> iota
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                                uint32_t mask, const uint32_t* __restrict__ offsets,
+                                                                uint32_t num_blocks) {
+  __shared__ uint32_t s_base[RS_BINS];        // next output slot of each digit for this block
+  __shared__ uint32_t s_wcnt[4][RS_BINS];     // per-wave digit counts of the current round
+  const int lane = gsr_lane(), wave = threadIdx.x >> 6;
+  s_base[threadIdx.x] = offsets[threadIdx.x * num_blocks + blockIdx.x];
+  const uint32_t base = blockIdx.x * RS_TILE;
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const uint32_t round_base = base + r * RS_THREADS;
+    if (round_base >= n) break;                               // uniform over the block
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t idx = round_base + threadIdx.x;
+    const bool valid = idx < n;
+    uint32_t key = 0, val = 0, digit = 0;
+    if (valid) {
+      key = keys_in[idx];
+      val = vals_in ? vals_in[idx] : idx;
+      digit = (key >> shift) & mask;
+    }
+    // lanes of this wave holding the same digit
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      uint64_t bit = __ballot((digit >> b) & 1u);
+      peers &= ((digit >> b) & 1u) ? bit : ~bit;
+    }
+    const int rank = gsr_mbcnt(peers);                       // peers below me
+    if (valid && rank == 0) s_wcnt[wave][digit] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+      uint32_t off = s_base[digit] + (uint32_t)rank;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w < wave) off += s_wcnt[w][digit];
+      keys_out[off] = key;
+      vals_out[off] = val;
+    }
+    __syncthreads();
+    s_base[threadIdx.x] += s_wcnt[0][threadIdx.x] + s_wcnt[1][threadIdx.x] + s_wcnt[2][threadIdx.x] + s_wcnt[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gsr_scan_workspace_bytes(int64_t n) { return scan_ws_bytes((uint64_t)(n < 0 ? 0 : n)); }
+
+int gsr_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_dev, void* workspace,
+                           size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || n > 0xFFFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!in || !out)) return GSR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < scan_ws_bytes((uint64_t)n) || (n > SCAN_TILE && !workspace)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  return scan_impl(in, out, (uint64_t)n, total_dev, reinterpret_cast<uint8_t*>(workspace), stream);
+}
+
+size_t gsr_sort_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  uint64_t nb = ((uint64_t)n + RS_TILE - 1) / RS_TILE;
+  size_t hist = ((nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
+  return hist + scan_ws_bytes(nb * RS_BINS);
+}
+
+// Sorts by key bits [begin_bit, end_bit).  Ping-pongs between (keys_a, vals_a) and (keys_b, vals_b); input is in
+// the *_a buffers (vals_are_iota != 0: the input values are 0..n-1 and vals_a is only scratch).  Returns (>= 0) 0 when the result is in the *_a
+// buffers and 1 when it is in the *_b buffers, or a negative error code.
+int gsr_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
+                       int vals_are_iota, int begin_bit, int end_bit, void* workspace, size_t workspace_bytes,
+                       void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || n > 0x7FFFFFFFll || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return GSR_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!keys_a || !vals_a || !keys_b || !vals_b)) return GSR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < gsr_sort_workspace_bytes(n) || !workspace) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  if (n == 0) return 0;
+  const uint32_t nb = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
+  size_t hist_bytes = (((size_t)nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
+  uint8_t* scan_ws = reinterpret_cast<uint8_t*>(workspace) + hist_bytes;
+
+  uint32_t* kin = keys_a; uint32_t* kout = keys_b;
+  const uint32_t* vin = vals_are_iota ? nullptr : vals_a; uint32_t* vout = vals_b;
+  int where = 0;
+  bool first = true;
+  for (int bit = begin_bit; bit < end_bit || first; bit += 8) {
+    int bits = end_bit - bit; if (bits > 8) bits = 8; if (bits < 0) bits = 0;
+    uint32_t mask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
+    rs_hist_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, hist, nb);
+    GSR_CHECK_LAUNCH();
+    int rc = scan_impl(hist, hist, (uint64_t)nb * RS_BINS, nullptr, scan_ws, stream);
+    if (rc != GSR_OK) return rc;
+    rs_scatter_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, vin, kout, vout, (uint32_t)n, bit, mask, hist, nb);
+    GSR_CHECK_LAUNCH();
+    where ^= 1;
+    if (where == 1) { kin = keys_b; vin = vals_b; kout = keys_a; vout = vals_a; }
+    else            { kin = keys_a; vin = vals_a; kout = keys_b; vout = vals_b; }
+    first = false;
+  }
+  return where;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""Boundary types of the rasterizer path.
+
+These mirror, field for field, what splat-trainer exchanges with ``taichi_splatting`` at
+the render boundary (reference call sites: ``splat_trainer/scene/mlp_scene.py:372-427``,
+``splat_trainer/trainer/trainer.py:291-320``, ``splat_trainer/controller/point_state.py:34-50``,
+``splat_trainer/scene/util.py:11-22``).  tensordict is not available here, so these are
+plain dataclasses over torch tensors exposing the attributes/methods the reference uses.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, fields, replace as _dc_replace
+from typing import Any, Optional, Tuple
+
+import torch
+
+
+@dataclass(frozen=True)
+class RasterConfig:
+  """Raster options.  The reference sets ``antialias``, ``blur_cov``, ``compute_visibility``
+  and ``compute_point_heuristic`` (trainer.py:305-310, mlp_scene.py:373); every keyword that
+  names a field here is routed into the config by ``pop_raster_config`` (scene/util.py:11-22).
+  """
+  tile_size: int = 16                 # pixels per tile side (one wave64 owns a tile, 2x2 px per lane)
+  margin_tiles: int = 3               # frustum-cull margin around the image, in tiles
+  alpha_threshold: float = 1.0 / 255.0
+  clamp_max_alpha: float = 0.99
+  saturate_threshold: float = 0.9999  # stop compositing a pixel once T < 1 - saturate_threshold
+  gaussian_scale: float = 3.0         # splat support: d^T conic d <= gaussian_scale^2
+  blur_cov: float = 0.3               # added to the 2D covariance diagonal
+  antialias: bool = False             # opacity *= sqrt(det(cov) / det(cov + aa_blur I))
+  aa_blur: float = 0.3                # anti-alias filter variance (px^2) used when antialias=True
+  compute_visibility: bool = False    # fill points.visibility (sum_pixels T*alpha) in forward
+  compute_point_heuristic: bool = False  # fill prune_cost / split_score in backward
+
+  @property
+  def transmittance_eps(self) -> float:
+    return 1.0 - self.saturate_threshold
+
+
+def pop_raster_config(options: dict) -> RasterConfig:
+  """Same contract as splat_trainer/scene/util.py:11-22: keys naming RasterConfig fields
+  are removed from ``options`` and used to build the config."""
+  keys = {f.name for f in fields(RasterConfig)}
+  raster_options = {k: v for k, v in options.items() if k in keys}
+  for k in raster_options:
+    del options[k]
+  return RasterConfig(**raster_options)
+
+
+@dataclass(frozen=True)
+class CameraParams:
+  """OpenCV-style pinhole (trainer.py:291-301, camera_table.py:167-175):
+  +z forward, ``uv = xy / z * f + c`` in pixels, pixel centres at +0.5."""
+  T_camera_world: torch.Tensor       # (4, 4)
+  projection: torch.Tensor           # (4,)  fx, fy, cx, cy  (pixels)
+  image_size: Tuple[int, int]        # (W, H)
+  near_plane: float = 0.1
+  far_plane: float = 100.0
+
+  def to(self, device=None, dtype=None) -> "CameraParams":
+    return _dc_replace(self,
+                       T_camera_world=self.T_camera_world.to(device=device, dtype=dtype),
+                       projection=self.projection.to(device=device, dtype=dtype))
+
+  @property
+  def device(self) -> torch.device:
+    return self.T_camera_world.device
+
+  @property
+  def camera_position(self) -> torch.Tensor:
+    R = self.T_camera_world[:3, :3]
+    t = self.T_camera_world[:3, 3]
+    return -(R.t() @ t)
+
+  @property
+  def focal_length(self) -> torch.Tensor:
+    return self.projection[0:2]
+
+  @property
+  def principal_point(self) -> torch.Tensor:
+    return self.projection[2:4]
+
+
+@dataclass
+class Gaussians3D:
+  """mlp_scene.py:401-407.  rotation is a quaternion in **xyzw** order (scene/io.py:102-104)."""
+  position: torch.Tensor      # (N, 3)
+  rotation: torch.Tensor      # (N, 4) xyzw
+  log_scaling: torch.Tensor   # (N, 3)
+  alpha_logit: torch.Tensor   # (N, 1)
+  feature: torch.Tensor       # (N, F) or (N, 3, K) SH coefficients
+
+  @property
+  def batch_size(self):
+    return (self.position.shape[0],)
+
+  @property
+  def device(self):
+    return self.position.device
+
+  def to(self, device=None, dtype=None) -> "Gaussians3D":
+    return Gaussians3D(**{f.name: getattr(self, f.name).to(device=device, dtype=dtype) for f in fields(self)})
+
+  def requires_grad_(self, flag: bool = True) -> "Gaussians3D":
+    for f in fields(self):
+      getattr(self, f.name).requires_grad_(flag)
+    return self
+
+
+def _index_rows(value: Any, rows: torch.Tensor) -> Any:
+  if value is None:
+    return None
+  if isinstance(value, torch.Tensor):
+    return value[rows]
+  if hasattr(value, "__getitem__"):
+    return value[rows]
+  return value
+
+
+def _detach(value: Any) -> Any:
+  if isinstance(value, torch.Tensor):
+    return value.detach()
+  if hasattr(value, "detach"):
+    return value.detach()
+  return value
+
+
+@dataclass
+class RenderedPoints:
+  """Per-point outputs for the M points that passed the frustum cull.
+
+  ``visibility`` is filled by the forward pass (compute_visibility); ``prune_cost`` and
+  ``split_score`` are owned by this object and filled **in place by backward**
+  (compute_point_heuristic) -- the reference reads them after ``loss.backward()``
+  (trainer.py:512-514).
+  """
+  idx: torch.Tensor                   # (M,) int64 indices into the scene's N points
+  depths: torch.Tensor                # (M, 1) camera-space z (differentiable)
+  opacity: torch.Tensor               # (M,)  (differentiable)
+  screen_scale: torch.Tensor          # (M, 2) sigma_major, sigma_minor in pixels
+  visibility: torch.Tensor            # (M,)
+  prune_cost: torch.Tensor            # (M,)
+  split_score: torch.Tensor           # (M,)
+  attributes: Any = None              # user payload (mlp_scene.py:423)
+
+  @property
+  def batch_size(self):
+    return (self.idx.shape[0],)
+
+  def replace(self, **kwargs) -> "RenderedPoints":
+    return _dc_replace(self, **kwargs)
+
+  def __getitem__(self, rows) -> "RenderedPoints":
+    return RenderedPoints(**{f.name: _index_rows(getattr(self, f.name), rows) for f in fields(self)})
+
+  @property
+  def visible_mask(self) -> torch.Tensor:
+    return self.visibility > 0
+
+  @property
+  def visible(self) -> "RenderedPoints":
+    return self[self.visible_mask.nonzero().squeeze(1)]
+
+  @property
+  def num_visible(self) -> int:
+    return int(self.visible_mask.sum().item())
+
+  def detach(self) -> "RenderedPoints":
+    return RenderedPoints(**{f.name: _detach(getattr(self, f.name)) for f in fields(self)})
+
+
+@dataclass
+class Rendering:
+  image: torch.Tensor                               # (H, W, C)
+  camera: CameraParams
+  points: RenderedPoints
+  median_depth_image: Optional[torch.Tensor] = None  # (H, W) when render_median_depth=True
+  final_transmittance: Optional[torch.Tensor] = None  # (H, W) T after the last composited splat
+  num_overlaps: int = 0                              # O = sum of tile overlaps (reported per frame)
+
+  @property
+  def image_size(self) -> Tuple[int, int]:
+    return self.camera.image_size
+
+  @property
+  def median_ndc_image(self) -> Optional[torch.Tensor]:
+    if self.median_depth_image is None:
+      return None
+    n, f = self.camera.near_plane, self.camera.far_plane
+    z = self.median_depth_image.clamp_min(n)
+    return (f * (z - n)) / (z * (f - n))
+
+  def detach(self) -> "Rendering":
+    return _dc_replace(self, image=self.image.detach(), points=self.points.detach(),
+                       median_depth_image=_detach(self.median_depth_image),
+                       final_transmittance=_detach(self.final_transmittance))

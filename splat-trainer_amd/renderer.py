@@ -1,0 +1,291 @@
+"""Host side of the rasterizer path: the three calls splat-trainer makes at the render boundary.
+
+    project_to_image(gaussians, camera_params, config) -> (gaussians2d, depth, indexes)
+    render_projected(indexes, gaussians2d, features, depth, camera_params, config, **options) -> Rendering
+    render_gaussians(gaussians, camera_params, config, use_sh=..., ...) -> Rendering
+
+Same names, argument meaning and outputs as the taichi_splatting calls at
+splat_trainer/scene/mlp_scene.py:375-378,415-419 and splat_trainer/scripts/test_split.py:30.
+Everything numerical happens in hand-written HIP kernels reached through the C ABI
+(include/gsplat_hip.h); PyTorch supplies device memory, the current stream and autograd plumbing.
+There is no CPU path: CPU tensors or a missing libgsplat_hip.so raise.
+
+Re-entrancy (the reference serialises taichi launches through TaichiQueue, train_scan.py:237,
+while the viewer thread renders concurrently, splatview.py:230-254): every call owns its
+workspaces and only enqueues on ``torch.cuda.current_stream()``; the library keeps no global
+state, so concurrent callers on different streams/threads are safe and no run_sync is needed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .data_types import CameraParams, Gaussians3D, RasterConfig, RenderedPoints, Rendering
+from .sh import evaluate_sh_at
+
+REC_FLOATS = 12
+PARTIAL_FLOATS = 12
+
+
+def _ptr(t: Optional[torch.Tensor]):
+  if t is None or t.numel() == 0:
+    return None
+  return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_device(*tensors: torch.Tensor):
+  for t in tensors:
+    if not t.is_cuda:
+      raise _lib.GsplatHipError(
+          "the rasterizer path runs only on a HIP device (got a CPU tensor); there is no CPU fallback")
+    if t.dtype not in (torch.float32, torch.int64, torch.int32):
+      raise TypeError(f"unsupported dtype {t.dtype}; the path computes in float32")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+  return t.detach().to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------- K1 + K2
+def frustum_cull(position: torch.Tensor, camera_params: CameraParams, config: RasterConfig) -> torch.Tensor:
+  """K1: ascending int64 indices of the points whose centre lies in the margin-expanded frustum."""
+  lib = _lib.load()
+  _require_device(position)
+  pos = _f32c(position)
+  N = pos.shape[0]
+  dev = pos.device
+  W, H = camera_params.image_size
+  T = _f32c(camera_params.T_camera_world)
+  proj = _f32c(camera_params.projection)
+  indexes = torch.empty(N, dtype=torch.int64, device=dev)
+  count = torch.zeros(1, dtype=torch.int32, device=dev)
+  ws_bytes = lib.gsr_cull_workspace_bytes(N)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+  _lib.check(lib.gsr_frustum_cull(_ptr(pos), N, _ptr(T), _ptr(proj), int(W), int(H),
+                                  float(camera_params.near_plane), float(camera_params.far_plane),
+                                  float(config.margin_tiles * config.tile_size), _ptr(indexes), _ptr(count),
+                                  _ptr(ws), ws_bytes, _stream()), "gsr_frustum_cull")
+  M = int(count.item())          # host sync #1: the index tensor's size is data dependent
+  return indexes[:M]
+
+
+class _ProjectFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, position, log_scaling, rotation, alpha_logit, indexes, T, proj, params):
+    lib = _lib.load()
+    pos, ls, rot, al = _f32c(position), _f32c(log_scaling), _f32c(rotation), _f32c(alpha_logit)
+    M = indexes.shape[0]
+    g2d = torch.empty(M, 6, dtype=torch.float32, device=pos.device)
+    depth = torch.empty(M, 1, dtype=torch.float32, device=pos.device)
+    _lib.check(lib.gsr_project_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M, _ptr(T),
+                                       _ptr(proj), C.byref(params), _ptr(g2d), _ptr(depth), _stream()),
+               "gsr_project_forward")
+    ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
+    ctx.params = params
+    return g2d, depth
+
+  @staticmethod
+  def backward(ctx, d_g2d, d_depth):
+    lib = _lib.load()
+    pos, ls, rot, al, indexes, T, proj = ctx.saved_tensors
+    M = indexes.shape[0]
+    d_pos = torch.zeros_like(pos)
+    d_ls = torch.zeros_like(ls)
+    d_rot = torch.zeros_like(rot)
+    d_al = torch.zeros_like(al)
+    if M > 0:
+      dg = _f32c(d_g2d) if d_g2d is not None else torch.zeros(M, 6, dtype=torch.float32, device=pos.device)
+      dd = _f32c(d_depth) if d_depth is not None else None
+      _lib.check(lib.gsr_project_backward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M, _ptr(T),
+                                          _ptr(proj), C.byref(ctx.params), _ptr(dg), _ptr(dd), _ptr(d_pos),
+                                          _ptr(d_ls), _ptr(d_rot), _ptr(d_al), _stream()),
+                 "gsr_project_backward")
+    return d_pos, d_ls, d_rot, d_al, None, None, None, None
+
+
+def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+  """K1 cull + K2 projection.  Returns ``gaussians2d (M,6) = [u v A B C opacity]``, ``depth (M,1)``,
+  ``indexes (M,) int64`` (ascending).  Differentiable wrt position / log_scaling / rotation /
+  alpha_logit; gradients land in N-sized tensors, zero outside ``indexes``."""
+  _require_device(gaussians.position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit)
+  indexes = frustum_cull(gaussians.position, camera_params, config)
+  T = _f32c(camera_params.T_camera_world)
+  proj = _f32c(camera_params.projection)
+  params = _lib.raster_params(config)
+  g2d, depth = _ProjectFn.apply(gaussians.position, gaussians.log_scaling, gaussians.rotation,
+                                gaussians.alpha_logit, indexes, T, proj, params)
+  return g2d, depth, indexes
+
+
+# ------------------------------------------------------------------------------------------- K4..K7
+class _RasterState:
+  """Per-frame buffers shared by forward and backward (owned by the autograd node / the Rendering)."""
+  __slots__ = ("M", "O", "C", "W", "H", "params", "rec", "order", "count", "offsets", "sorted_rank",
+               "sorted_inst", "tile_range", "vis_partial", "final_T", "last", "median", "visibility",
+               "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad")
+
+
+def _u32(n: int, device) -> torch.Tensor:
+  return torch.empty(max(n, 1), dtype=torch.int32, device=device)   # raw storage for uint32 arrays
+
+
+def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tensor, st: _RasterState,
+                       need_vis_partial: bool) -> torch.Tensor:
+  lib = _lib.load()
+  dev = g2d.device
+  M, C_, W, H = st.M, st.C, st.W, st.H
+  stream = _stream()
+  tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
+  num_tiles = tiles_x * tiles_y
+  image = torch.zeros(H, W, C_, dtype=torch.float32, device=dev)
+  st.final_T = torch.ones(H, W, dtype=torch.float32, device=dev)
+  st.last = torch.zeros(H, W, dtype=torch.int32, device=dev)
+  st.median = torch.zeros(H, W, dtype=torch.float32, device=dev) if st.want_median else None
+  st.visibility = torch.zeros(M, dtype=torch.float32, device=dev)
+  st.prune_cost = torch.zeros(M, dtype=torch.float32, device=dev)
+  st.split_score = torch.zeros(M, dtype=torch.float32, device=dev)
+  st.screen_scale = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+  st.O = 0
+  if M == 0:
+    return image
+
+  # depth order of the M splats (stable: ties keep ascending index)
+  keys_a, keys_b, vals_a, vals_b = _u32(M, dev), _u32(M, dev), _u32(M, dev), _u32(M, dev)
+  sort_bytes = lib.gsr_sort_workspace_bytes(M)
+  sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
+  _lib.check(lib.gsr_depth_keys(_ptr(depth), M, _ptr(keys_a), stream), "gsr_depth_keys")
+  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, 32,
+                                            _ptr(sort_ws), sort_bytes, stream), "gsr_sort_pairs_u32(depth)")
+  st.order = vals_b if where == 1 else vals_a
+
+  # per-splat tile counts + depth-ordered records
+  st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
+  st.count = _u32(M, dev)
+  st.offsets = _u32(M, dev)
+  total = torch.zeros(1, dtype=torch.int32, device=dev)
+  _lib.check(lib.gsr_tile_count(_ptr(g2d), _ptr(depth), _ptr(feats), _ptr(st.order), M, C_, W, H,
+                                C.byref(st.params), _ptr(st.rec), _ptr(st.count), _ptr(st.screen_scale), stream),
+             "gsr_tile_count")
+  scan_bytes = lib.gsr_scan_workspace_bytes(M)
+  scan_ws = torch.empty(scan_bytes, dtype=torch.uint8, device=dev)
+  _lib.check(lib.gsr_exclusive_scan_u32(_ptr(st.count), _ptr(st.offsets), M, _ptr(total), _ptr(scan_ws),
+                                        scan_bytes, stream), "gsr_exclusive_scan_u32")
+  O = int(total.item())          # host sync #2: number of (tile, splat) overlaps sizes the sort buffers
+  if O < 0:
+    raise _lib.GsplatHipError("tile overlap count overflowed 2^31")
+  st.O = O
+  if O == 0:
+    return image
+
+  # emit (tile id, instance) in depth order, stable-sort by tile id, find per-tile ranges
+  tkeys_a, tkeys_b, tvals_a, tvals_b = _u32(O, dev), _u32(O, dev), _u32(O, dev), _u32(O, dev)
+  inst2rank = _u32(O, dev)
+  _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
+                               _ptr(inst2rank), stream), "gsr_tile_emit")
+  tile_bits = max(1, int(math.ceil(math.log2(num_tiles)))) if num_tiles > 1 else 1
+  tsort_bytes = lib.gsr_sort_workspace_bytes(O)
+  tsort_ws = torch.empty(tsort_bytes, dtype=torch.uint8, device=dev)
+  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(tkeys_a), _ptr(tvals_a), _ptr(tkeys_b), _ptr(tvals_b), O, 1, 0,
+                                            tile_bits, _ptr(tsort_ws), tsort_bytes, stream),
+                     "gsr_sort_pairs_u32(tile)")
+  sorted_keys, st.sorted_inst = (tkeys_b, tvals_b) if where == 1 else (tkeys_a, tvals_a)
+  st.tile_range = torch.zeros(num_tiles, 2, dtype=torch.int32, device=dev)
+  st.sorted_rank = _u32(O, dev)
+  _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), _ptr(st.sorted_inst), _ptr(inst2rank), O, num_tiles,
+                                 _ptr(st.tile_range), _ptr(st.sorted_rank), stream), "gsr_tile_ranges")
+
+  st.vis_partial = torch.zeros(O, dtype=torch.float32, device=dev) if need_vis_partial else None
+  _lib.check(lib.gsr_composite_forward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
+                                       _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
+                                       _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
+                                       stream), "gsr_composite_forward")
+  if st.compute_visibility:
+    _lib.check(lib.gsr_reduce_visibility(_ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count), _ptr(st.order),
+                                         M, _ptr(st.visibility), stream), "gsr_reduce_visibility")
+  return image
+
+
+class _RasterFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, g2d, feats, depth, st: _RasterState):
+    g, f, d = _f32c(g2d), _f32c(feats), _f32c(depth).reshape(-1)
+    image = _bin_and_composite(g, f, d, st, need_vis_partial=st.compute_visibility or st.needs_grad)
+    ctx.st = st
+    return image
+
+  @staticmethod
+  def backward(ctx, d_image):
+    lib = _lib.load()
+    st: _RasterState = ctx.st
+    dev = d_image.device
+    d_g2d = torch.zeros(st.M, 6, dtype=torch.float32, device=dev)
+    d_feat = torch.zeros(st.M, st.C, dtype=torch.float32, device=dev)
+    if st.M > 0 and st.O > 0:
+      if st.vis_partial is None:
+        raise _lib.GsplatHipError("backward called on a rendering made without gradient state")
+      stream = _stream()
+      dimg = _f32c(d_image)
+      partial = torch.empty(st.O, PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+      _lib.check(lib.gsr_composite_backward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
+                                            _ptr(st.vis_partial), _ptr(st.tile_range), st.W, st.H, st.C,
+                                            C.byref(st.params), _ptr(st.final_T), _ptr(st.last), _ptr(dimg),
+                                            _ptr(partial), stream), "gsr_composite_backward")
+      # prune_cost / split_score are written straight into the tensors the Rendering already holds
+      _lib.check(lib.gsr_reduce_gradients(_ptr(partial), _ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count),
+                                          _ptr(st.order), st.M, st.C, _ptr(d_g2d), _ptr(d_feat),
+                                          _ptr(st.prune_cost), _ptr(st.split_score), stream),
+                 "gsr_reduce_gradients")
+    return d_g2d, d_feat, None, None
+
+
+def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features: torch.Tensor,
+                     depth: torch.Tensor, camera_params: CameraParams, config: RasterConfig,
+                     render_median_depth: bool = False, **_unused) -> Rendering:
+  """K4 tile binning -> K5 radix sort -> K6 composite; autograd backward = K7 (+ per-point heuristics).
+
+  ``features`` is (M, C) with C in {1, 2, 3}.  ``points.prune_cost`` / ``points.split_score`` of the
+  returned Rendering are filled in place when ``loss.backward()`` runs (trainer.py:512-514 reads them
+  afterwards); ``points.visibility`` is available right after the forward pass (reg_loss,
+  mlp_scene.py:268-288, needs ``points.visible`` before backward)."""
+  _require_device(gaussians2d, features, depth)
+  if features.dim() != 2 or not (1 <= features.shape[1] <= 3):
+    raise ValueError(f"features must be (M, C) with C in 1..3, got {tuple(features.shape)}")
+  if config.tile_size != 16:
+    raise ValueError("the HIP kernels are specialised for tile_size=16")
+  W, H = camera_params.image_size
+  st = _RasterState()
+  st.M, st.C, st.W, st.H = int(gaussians2d.shape[0]), int(features.shape[1]), int(W), int(H)
+  st.params = _lib.raster_params(config)
+  st.want_median = bool(render_median_depth)
+  st.compute_visibility = bool(config.compute_visibility or config.compute_point_heuristic)
+  st.vis_partial = None
+  st.needs_grad = torch.is_grad_enabled() and (gaussians2d.requires_grad or features.requires_grad)
+  image = _RasterFn.apply(gaussians2d, features, depth, st)
+  points = RenderedPoints(idx=indexes, depths=depth, opacity=gaussians2d[:, 5], screen_scale=st.screen_scale,
+                          visibility=st.visibility, prune_cost=st.prune_cost, split_score=st.split_score)
+  return Rendering(image=image, camera=camera_params, points=points, median_depth_image=st.median,
+                   final_transmittance=st.final_T, num_overlaps=st.O)
+
+
+def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config: Optional[RasterConfig] = None,
+                     use_sh: bool = False, render_median_depth: bool = False, **options) -> Rendering:
+  """One-call form (splat_trainer/scripts/test_split.py:30): project -> colour -> rasterize.
+  ``use_sh``: ``gaussians.feature`` is (N, 3, K) SH coefficients evaluated towards the camera;
+  otherwise it is an (N, C) per-point colour."""
+  config = config or RasterConfig()
+  g2d, depth, indexes = project_to_image(gaussians, camera_params, config)
+  if use_sh:
+    feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_params.camera_position)
+  else:
+    feats = gaussians.feature[indexes]
+  return render_projected(indexes, g2d, feats, depth, camera_params, config,
+                          render_median_depth=render_median_depth, **options)

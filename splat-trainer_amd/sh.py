@@ -1,0 +1,69 @@
+"""evaluate_sh_at: view-dependent colour from spherical-harmonic coefficients (K3).
+
+Call site in the reference: splat_trainer/scene/transfer_sh.py:49
+``colors = evaluate_sh_at(self.sh_features, positions, indexes, cam_pos)   # N, 3``
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+  if t is None or t.numel() == 0:
+    return None
+  return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _SHFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, sh_features, positions, indexes, camera_pos):
+    lib = _lib.load()
+    sh = sh_features.detach().to(torch.float32).contiguous()
+    pos = positions.detach().to(torch.float32).contiguous()
+    cam = camera_pos.detach().to(torch.float32).contiguous()
+    idx = indexes.contiguous()
+    M, K = idx.shape[0], sh.shape[2]
+    out = torch.empty(M, 3, dtype=torch.float32, device=sh.device)
+    _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(out), _stream()),
+               "gsr_sh_forward")
+    ctx.save_for_backward(pos, idx, cam)
+    ctx.shape = tuple(sh.shape)
+    return out
+
+  @staticmethod
+  def backward(ctx, d_out):
+    lib = _lib.load()
+    pos, idx, cam = ctx.saved_tensors
+    N, _, K = ctx.shape
+    d_sh = torch.zeros(N, 3, K, dtype=torch.float32, device=pos.device)
+    M = idx.shape[0]
+    if M > 0:
+      g = d_out.detach().to(torch.float32).contiguous()
+      _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(d_sh), _stream()),
+                 "gsr_sh_backward")
+    return d_sh, None, None, None
+
+
+def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: torch.Tensor,
+                   camera_pos: torch.Tensor) -> torch.Tensor:
+  """``sh_features (N,3,K)``, ``positions (N,3)``, ``indexes (M,) int64``, ``camera_pos (3,)`` -> ``(M,3)``.
+
+  colour_c = 0.5 + sum_k sh[idx, c, k] * Y_k(normalize(positions[idx] - camera_pos)), K in {1,4,9,16}
+  (degrees 0..3, basis order k = n(n+1)+m as splat_trainer/scene/mlp/rsh.py).  Differentiable wrt
+  ``sh_features``; the caller clamps (transfer_sh.py:50)."""
+  for t in (sh_features, positions, indexes, camera_pos):
+    if not t.is_cuda:
+      raise _lib.GsplatHipError("evaluate_sh_at runs only on a HIP device; there is no CPU fallback")
+  if sh_features.dim() != 3 or sh_features.shape[1] != 3 or sh_features.shape[2] not in (1, 4, 9, 16):
+    raise ValueError(f"sh_features must be (N,3,K) with K in (1,4,9,16), got {tuple(sh_features.shape)}")
+  if indexes.dtype != torch.int64:
+    raise TypeError("indexes must be int64")
+  return _SHFn.apply(sh_features, positions, indexes, camera_pos)

@@ -1,0 +1,69 @@
+"""Shared helpers for the parity tests (oracle = oracle/torch_oracle.py; product = splat_trainer_amd)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from oracle import torch_oracle as oracle  # noqa: E402  (test infrastructure only)
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+  """max |a-b| relative to the reference tensor's max magnitude (the 1e-4-rel criterion of BASELINE.json,
+  measured against the tensor scale so that near-zero entries do not dominate)."""
+  a, b = a.detach().double().cpu(), b.detach().double().cpu()
+  scale = max(b.abs().max().item(), 1e-30)
+  return (a - b).abs().max().item() / scale
+
+
+def small_scene(n=400, w=64, h=48, sh_degree=0, seed=3, sigma_px=3.0):
+  import splat_trainer_amd.synthetic as syn
+  return syn.scene_a(n, w, h, sh_degree=sh_degree, seed=seed, sigma_px=sigma_px)
+
+
+def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, dtype=torch.float32):
+  """Oracle forward + MSE loss + autograd backward + analytic per-point heuristics."""
+  pos = g.position.clone().to(dtype).requires_grad_(True)
+  ls = g.log_scaling.clone().to(dtype).requires_grad_(True)
+  rot = g.rotation.clone().to(dtype).requires_grad_(True)
+  al = g.alpha_logit.clone().to(dtype).requires_grad_(True)
+  feat = g.feature.clone().to(dtype).requires_grad_(True)
+  T = cam.T_camera_world.to(dtype)
+  proj = cam.projection.to(dtype)
+  out, g2d, depth, sscale, idx = oracle.render(pos, ls, rot, al, feat, T, proj, cam.image_size, cam.near_plane,
+                                                cam.far_plane, config, use_sh=use_sh, want_median=want_median)
+  image = out.image
+  image.retain_grad()
+  g2d.retain_grad()
+  loss = ((image.clamp(0, 1) - target) ** 2).mean()
+  loss.backward()
+  # heuristics need the incoming image gradient
+  if use_sh:
+    R = T[:3, :3]
+    feats = oracle.evaluate_sh_at(feat.detach(), pos.detach(), idx, -(R.t() @ T[:3, 3]))
+  else:
+    feats = feat.detach()[idx]
+  heur = oracle.rasterize(g2d.detach(), depth.detach(), feats, cam.image_size, config, dL_dimage=image.grad)
+  return dict(image=image.detach(), final_T=out.final_T, visibility=out.visibility, median=out.median_depth,
+              g2d=g2d.detach(), d_g2d=g2d.grad, depth=depth.detach(), screen_scale=sscale, idx=idx, loss=loss.detach(),
+              d_position=pos.grad, d_log_scaling=ls.grad, d_rotation=rot.grad, d_alpha_logit=al.grad,
+              d_feature=feat.grad, prune_cost=heur.prune_cost, split_score=heur.split_score,
+              num_overlaps=out.num_overlaps)
+
+
+def hip_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, device="cuda"):
+  import splat_trainer_amd as sta
+  gd = sta.Gaussians3D(*(t.clone().to(device).requires_grad_(True) for t in
+                         (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+  camd = cam.to(device)
+  r = sta.render_gaussians(gd, camd, config, use_sh=use_sh, render_median_depth=want_median)
+  loss = ((r.image.clamp(0, 1) - target) ** 2).mean()
+  loss.backward()
+  return dict(rendering=r, image=r.image.detach(), final_T=r.final_transmittance, visibility=r.points.visibility,
+              median=r.median_depth_image, depth=r.points.depths.detach(), screen_scale=r.points.screen_scale,
+              idx=r.points.idx, loss=loss.detach(), d_position=gd.position.grad, d_log_scaling=gd.log_scaling.grad,
+              d_rotation=gd.rotation.grad, d_alpha_logit=gd.alpha_logit.grad, d_feature=gd.feature.grad,
+              prune_cost=r.points.prune_cost, split_score=r.points.split_score, num_overlaps=r.num_overlaps)

@@ -1,0 +1,114 @@
+"""The C-ABI library loads and exports every symbol include/gsplat_hip.h declares (no compute calls: there
+is no GPU here), the ctypes binding covers exactly that set, the product path refuses CPU tensors and a
+missing library (no fallback), and the boundary types behave as the reference's consumers expect."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import splat_trainer_amd as sta
+from splat_trainer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+  text = open(os.path.join(ROOT, "include", "gsplat_hip.h")).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_libs):
+  lib = C.CDLL(built_libs[0])
+  syms = _header_symbols()
+  assert len(syms) >= 20
+  for s in syms:
+    assert hasattr(lib, s), f"{s} declared in gsplat_hip.h but not exported"
+  assert sorted(_lib.PROTOTYPES) == syms, "ctypes binding and header disagree"
+
+
+def test_host_only_entry_points(built_libs):
+  lib = _lib.load()
+  assert lib.gsr_abi_version() == _lib.ABI_VERSION
+  assert lib.gsr_error_string(-2).decode() == "workspace too small"
+  assert lib.gsr_sort_workspace_bytes(0) > 0
+  assert lib.gsr_sort_workspace_bytes(10_000_000) >= (10_000_000 // 4096) * 256 * 4
+  assert lib.gsr_scan_workspace_bytes(5_000_000) >= 256
+  assert lib.gsr_cull_workspace_bytes(3_000_000) >= (3_000_000 // 1024) * 4
+  p = _lib.raster_params(sta.RasterConfig(antialias=True, blur_cov=0.0))
+  assert abs(p.blur - 0.3) < 1e-7 and p.antialias == 1 and p.tile_size == 16 and abs(p.q_max - 9.0) < 1e-6
+  assert C.sizeof(_lib.GsrRasterParamsC) == 32
+
+
+def test_no_cpu_fallback():
+  g = sta.Gaussians3D(torch.randn(4, 3), torch.randn(4, 4), torch.randn(4, 3), torch.randn(4, 1), torch.randn(4, 3))
+  cam = sta.CameraParams(torch.eye(4), torch.tensor([50., 50., 16., 16.]), (32, 32))
+  with pytest.raises(sta.GsplatHipError):
+    sta.project_to_image(g, cam, sta.RasterConfig())
+  with pytest.raises(sta.GsplatHipError):
+    sta.evaluate_sh_at(torch.randn(4, 3, 1), torch.randn(4, 3), torch.arange(4), torch.zeros(3))
+  with pytest.raises(sta.GsplatHipError):
+    sta.render_projected(torch.arange(4), torch.randn(4, 6), torch.randn(4, 3), torch.rand(4, 1), cam, sta.RasterConfig())
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+  monkeypatch.setattr(_lib, "_lib", None)
+  monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+  with pytest.raises(sta.GsplatHipError, match="no CPU fallback"):
+    _lib.load()
+
+
+def test_product_never_imports_oracle():
+  pkg = os.path.join(ROOT, "splat-trainer_amd")
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(".py"):
+        src = open(os.path.join(dirpath, f)).read()
+        assert not re.search(r"^\s*(import|from)\s+\.*oracle", src, flags=re.M), f
+        assert "torch_oracle" not in src, f
+
+
+def test_pop_raster_config_contract():
+  opts = dict(antialias=True, blur_cov=0.0, compute_visibility=True, compute_point_heuristic=True,
+              render_median_depth=True, specular_weight=0.5)
+  cfg = sta.pop_raster_config(opts)
+  assert cfg.antialias and cfg.compute_visibility and cfg.compute_point_heuristic and cfg.blur_cov == 0.0
+  assert opts == dict(render_median_depth=True, specular_weight=0.5)
+
+
+def test_camera_params_and_rendered_points():
+  T = torch.eye(4); T[:3, 3] = torch.tensor([1., 2., 3.])
+  cam = sta.CameraParams(T, torch.tensor([10., 11., 4., 5.]), (8, 6), 0.1, 50.0).to("cpu", torch.float32)
+  assert torch.allclose(cam.camera_position, torch.tensor([-1., -2., -3.]))
+  M = 5
+  vis = torch.tensor([0., 1., 0., 2., 3.])
+  pts = sta.RenderedPoints(idx=torch.arange(M) * 2, depths=torch.rand(M, 1), opacity=torch.rand(M),
+                           screen_scale=torch.rand(M, 2), visibility=vis, prune_cost=torch.zeros(M),
+                           split_score=torch.zeros(M))
+  assert pts.num_visible == 3
+  v = pts.visible
+  assert v.idx.tolist() == [2, 6, 8] and v.depths.shape == (3, 1) and v.batch_size == (3,)
+  pts2 = pts.replace(attributes=dict(a=1))
+  assert pts2.attributes == dict(a=1) and pts.attributes is None
+  r = sta.Rendering(image=torch.rand(6, 8, 3, requires_grad=True), camera=cam, points=pts,
+                    median_depth_image=torch.rand(6, 8) + 0.2)
+  d = r.detach()
+  assert not d.image.requires_grad and d.image_size == (8, 6)
+  assert d.median_ndc_image.shape == (6, 8)
+
+
+def test_point_state_consumes_rendered_points():
+  from splat_trainer_amd.controller_math import PointState, find_split_prune_indexes
+  torch.manual_seed(0)
+  N, M = 50, 20
+  st = PointState.new_zeros(N, "cpu")
+  for _ in range(6):
+    idx = torch.randperm(N)[:M].sort().values
+    pts = sta.RenderedPoints(idx=idx, depths=torch.rand(M, 1), opacity=torch.rand(M), screen_scale=torch.rand(M, 2) * 10,
+                             visibility=torch.rand(M) * (torch.rand(M) > 0.3), prune_cost=torch.rand(M),
+                             split_score=torch.rand(M))
+    st.add_rendering(sta.Rendering(image=torch.zeros(2, 2, 3), camera=None, points=pts))
+  split, prune = find_split_prune_indexes(st, t=0.2, target_points=60, min_views=1)
+  assert split.dtype == torch.bool and not (split & prune).any() and split.sum() > 0

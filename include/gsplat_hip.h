@@ -93,8 +93,11 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
 /* sh_features [N,3,K], K in {1,4,9,16}; colour = 0.5 + sum_k sh[c][k] Y_k(normalize(p - camera_pos)). */
 int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
                    const float* camera_pos, float* colors_out, void* stream);
-int gsr_sh_backward(const float* dL_dcolors, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
-                    const float* camera_pos, float* d_sh_features, void* stream);
+/* d_sh_features [N,3,K] and d_positions [N,3] (may be NULL): rows ``indexes`` are written, pass zeros.
+ * d_positions is the gradient through the view direction normalize(p - camera_pos). */
+int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const float* positions, const int64_t* indexes,
+                    int64_t M, int32_t K, const float* camera_pos, float* d_sh_features, float* d_positions,
+                    void* stream);
 
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */
 /* depth -> sortable u32 keys */

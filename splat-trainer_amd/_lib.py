@@ -45,7 +45,7 @@ PROTOTYPES = {
     "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p]),
     "gsr_project_backward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
-    "gsr_sh_backward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "gsr_sh_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     "gsr_depth_keys": (C.c_int, [_p, _i64, _p, _p]),
     "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p]),
     "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),

@@ -138,20 +138,23 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ dcol, const float* __restrict__ pos,
-                                                     const int64_t* __restrict__ idx, int64_t M,
-                                                     const float* __restrict__ cam_pos, float* __restrict__ dsh) {
+__global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ dcol, const float* __restrict__ sh,
+                                                     const float* __restrict__ pos, const int64_t* __restrict__ idx,
+                                                     int64_t M, const float* __restrict__ cam_pos,
+                                                     float* __restrict__ dsh, float* __restrict__ dpos) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const int64_t i = idx[m];
-  float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
-  float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+  float vx = pos[3 * i] - cam_pos[0], vy = pos[3 * i + 1] - cam_pos[1], vz = pos[3 * i + 2] - cam_pos[2];
+  float inv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
+  const float x = vx * inv, y = vy * inv, z = vz * inv;
   float Y[K];
-  gsr_sh_basis<K>(dx * inv, dy * inv, dz * inv, Y);
+  gsr_sh_basis<K>(x, y, z, Y);
   float* row = dsh + (int64_t)3 * K * i;
+  const float g3[3] = {dcol[3 * m], dcol[3 * m + 1], dcol[3 * m + 2]};
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    const float g = dcol[3 * m + ch];
+    const float g = g3[ch];
     if (K % 4 == 0) {
 #pragma unroll
       for (int k = 0; k < K; k += 4)
@@ -160,6 +163,25 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ d
 #pragma unroll
       for (int k = 0; k < K; ++k) row[ch * K + k] = g * Y[k];
     }
+  }
+  if (dpos != nullptr && K > 1) {
+    // colour depends on the point through the view direction d = v/|v|:  dL/dp = (I - d d^T)/|v| * dL/dd
+    float dYx[K], dYy[K], dYz[K];
+    gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
+    const float* c = sh + (int64_t)3 * K * i;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+      for (int k = 1; k < K; ++k) {
+        const float w = g3[ch] * c[ch * K + k];
+        gx += w * dYx[k]; gy += w * dYy[k]; gz += w * dYz[k];
+      }
+    }
+    const float dot = gx * x + gy * y + gz * z;
+    dpos[3 * i] = (gx - x * dot) * inv;
+    dpos[3 * i + 1] = (gy - y * dot) * inv;
+    dpos[3 * i + 2] = (gz - z * dot) * inv;
   }
 }
 
@@ -273,19 +295,21 @@ int gsr_sh_forward(const float* sh_features, const float* positions, const int64
   return GSR_OK;
 }
 
-int gsr_sh_backward(const float* dL_dcolors, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
-                    const float* camera_pos, float* d_sh_features, void* stream_) {
+int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const float* positions, const int64_t* indexes,
+                    int64_t M, int32_t K, const float* camera_pos, float* d_sh_features, float* d_positions,
+                    void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!dL_dcolors || !positions || !indexes || !camera_pos || !d_sh_features) return GSR_ERR_INVALID_ARGUMENT;
+  if (!dL_dcolors || !sh_features || !positions || !indexes || !camera_pos || !d_sh_features)
+    return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
   switch (K) {
-    case 1: sh_bwd_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
-    case 4: sh_bwd_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
-    case 9: sh_bwd_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
-    default: sh_bwd_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors, positions, indexes, M, camera_pos, d_sh_features); break;
+    case 1: sh_bwd_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
+    case 4: sh_bwd_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
+    case 9: sh_bwd_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
+    default: sh_bwd_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
   }
   GSR_CHECK_LAUNCH();
   return GSR_OK;

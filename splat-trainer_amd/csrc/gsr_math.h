@@ -262,6 +262,40 @@ GSR_HD void gsr_sh_basis(float x, float y, float z, float* Y) {
   }
 }
 
+// Polynomial partial derivatives of the basis wrt the (unit) direction components; the caller chains
+// them through the normalisation d = v/|v|.
+template <int K>
+GSR_HD void gsr_sh_basis_grad(float x, float y, float z, float* dx, float* dy, float* dz) {
+  dx[0] = dy[0] = dz[0] = 0.f;
+  if (K > 1) {
+    dx[1] = 0.f;         dy[1] = -GSR_SH_C1; dz[1] = 0.f;
+    dx[2] = 0.f;         dy[2] = 0.f;        dz[2] = GSR_SH_C1;
+    dx[3] = -GSR_SH_C1;  dy[3] = 0.f;        dz[3] = 0.f;
+  }
+  if (K > 4) {
+    const float c0 = 1.0925484305920792f, c1 = -1.0925484305920792f, c2 = 0.31539156525252005f,
+                c3 = -1.0925484305920792f, c4 = 0.5462742152960396f;
+    dx[4] = c0 * y;         dy[4] = c0 * x;         dz[4] = 0.f;
+    dx[5] = 0.f;            dy[5] = c1 * z;         dz[5] = c1 * y;
+    dx[6] = -2.f * c2 * x;  dy[6] = -2.f * c2 * y;  dz[6] = 4.f * c2 * z;
+    dx[7] = c3 * z;         dy[7] = 0.f;            dz[7] = c3 * x;
+    dx[8] = 2.f * c4 * x;   dy[8] = -2.f * c4 * y;  dz[8] = 0.f;
+    if (K > 9) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      const float e0 = -0.5900435899266435f, e1 = 2.890611442640554f, e2 = -0.4570457994644658f,
+                  e3 = 0.3731763325901154f, e4 = -0.4570457994644658f, e5 = 1.445305721320277f,
+                  e6 = -0.5900435899266435f;
+      dx[9]  = 6.f * e0 * xy;                dy[9]  = e0 * (3.f * xx - 3.f * yy);       dz[9]  = 0.f;
+      dx[10] = e1 * yz;                      dy[10] = e1 * xz;                          dz[10] = e1 * xy;
+      dx[11] = -2.f * e2 * xy;               dy[11] = e2 * (4.f * zz - xx - 3.f * yy);  dz[11] = 8.f * e2 * yz;
+      dx[12] = -6.f * e3 * xz;               dy[12] = -6.f * e3 * yz;                   dz[12] = e3 * (6.f * zz - 3.f * xx - 3.f * yy);
+      dx[13] = e4 * (4.f * zz - 3.f * xx - yy); dy[13] = -2.f * e4 * xy;                dz[13] = 8.f * e4 * xz;
+      dx[14] = 2.f * e5 * xz;                dy[14] = -2.f * e5 * yz;                   dz[14] = e5 * (xx - yy);
+      dx[15] = e6 * (3.f * xx - 3.f * yy);   dy[15] = -6.f * e6 * xy;                   dz[15] = 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ tile binning maths (K4)
 struct GsrExtent {            // half-open tile rectangle [x0,x1) x [y0,y1) and the effective support
   int x0, x1, y0, y1;

@@ -31,6 +31,37 @@ REC_FLOATS = 12
 PARTIAL_FLOATS = 12
 
 
+class KernelTimer:
+  """HIP-event timing of individual kernels on the stream they are launched on (bench.py's roofline leg).
+  Off by default (``renderer.KERNEL_TIMER = None``); recording costs two event records per timed launch."""
+
+  def __init__(self):
+    self.events = {}
+    self._open = {}
+
+  def begin(self, name: str):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(torch.cuda.current_stream())
+    self._open[name] = e
+
+  def end(self, name: str):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(torch.cuda.current_stream())
+    self.events.setdefault(name, []).append((self._open.pop(name), e))
+
+  def summary(self) -> dict:
+    """name -> (launches, average milliseconds).  Synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in self.events.items()}
+
+  def reset(self):
+    self.events.clear()
+    self._open.clear()
+
+
+KERNEL_TIMER: Optional[KernelTimer] = None
+
+
 def _ptr(t: Optional[torch.Tensor]):
   if t is None or t.numel() == 0:
     return None
@@ -204,10 +235,15 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
                                  _ptr(st.tile_range), _ptr(st.sorted_rank), stream), "gsr_tile_ranges")
 
   st.vis_partial = torch.zeros(O, dtype=torch.float32, device=dev) if need_vis_partial else None
+  timer = KERNEL_TIMER
+  if timer is not None:
+    timer.begin("composite_forward")
   _lib.check(lib.gsr_composite_forward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
                                        _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
                                        _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
                                        stream), "gsr_composite_forward")
+  if timer is not None:
+    timer.end("composite_forward")
   if st.compute_visibility:
     _lib.check(lib.gsr_reduce_visibility(_ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count), _ptr(st.order),
                                          M, _ptr(st.visibility), stream), "gsr_reduce_visibility")
@@ -235,10 +271,15 @@ class _RasterFn(torch.autograd.Function):
       stream = _stream()
       dimg = _f32c(d_image)
       partial = torch.empty(st.O, PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+      timer = KERNEL_TIMER
+      if timer is not None:
+        timer.begin("composite_backward")
       _lib.check(lib.gsr_composite_backward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
                                             _ptr(st.vis_partial), _ptr(st.tile_range), st.W, st.H, st.C,
                                             C.byref(st.params), _ptr(st.final_T), _ptr(st.last), _ptr(dimg),
                                             _ptr(partial), stream), "gsr_composite_backward")
+      if timer is not None:
+        timer.end("composite_backward")
       # prune_cost / split_score are written straight into the tensors the Rendering already holds
       _lib.check(lib.gsr_reduce_gradients(_ptr(partial), _ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count),
                                           _ptr(st.order), st.M, st.C, _ptr(d_g2d), _ptr(d_feat),

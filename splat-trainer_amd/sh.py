@@ -34,22 +34,22 @@ class _SHFn(torch.autograd.Function):
     out = torch.empty(M, 3, dtype=torch.float32, device=sh.device)
     _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(out), _stream()),
                "gsr_sh_forward")
-    ctx.save_for_backward(pos, idx, cam)
-    ctx.shape = tuple(sh.shape)
+    ctx.save_for_backward(sh, pos, idx, cam)
     return out
 
   @staticmethod
   def backward(ctx, d_out):
     lib = _lib.load()
-    pos, idx, cam = ctx.saved_tensors
-    N, _, K = ctx.shape
+    sh, pos, idx, cam = ctx.saved_tensors
+    N, _, K = sh.shape
     d_sh = torch.zeros(N, 3, K, dtype=torch.float32, device=pos.device)
+    d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[1] else None
     M = idx.shape[0]
     if M > 0:
       g = d_out.detach().to(torch.float32).contiguous()
-      _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(d_sh), _stream()),
-                 "gsr_sh_backward")
-    return d_sh, None, None, None
+      _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(d_sh),
+                                     _ptr(d_pos), _stream()), "gsr_sh_backward")
+    return d_sh, d_pos, None, None
 
 
 def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: torch.Tensor,
@@ -58,7 +58,7 @@ def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: 
 
   colour_c = 0.5 + sum_k sh[idx, c, k] * Y_k(normalize(positions[idx] - camera_pos)), K in {1,4,9,16}
   (degrees 0..3, basis order k = n(n+1)+m as splat_trainer/scene/mlp/rsh.py).  Differentiable wrt
-  ``sh_features``; the caller clamps (transfer_sh.py:50)."""
+  ``sh_features`` and, through the view direction, ``positions``; the caller clamps (transfer_sh.py:50)."""
   for t in (sh_features, positions, indexes, camera_pos):
     if not t.is_cuda:
       raise _lib.GsplatHipError("evaluate_sh_at runs only on a HIP device; there is no CPU fallback")

@@ -24,7 +24,8 @@ def small_scene(n=400, w=64, h=48, sh_degree=0, seed=3, sigma_px=3.0):
   return syn.scene_a(n, w, h, sh_degree=sh_degree, seed=seed, sigma_px=sigma_px)
 
 
-def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, dtype=torch.float32):
+def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, dtype=torch.float32,
+                            loss_scale=1.0):
   """Oracle forward + MSE loss + autograd backward + analytic per-point heuristics."""
   pos = g.position.clone().to(dtype).requires_grad_(True)
   ls = g.log_scaling.clone().to(dtype).requires_grad_(True)
@@ -38,7 +39,7 @@ def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=Fals
   image = out.image
   image.retain_grad()
   g2d.retain_grad()
-  loss = ((image.clamp(0, 1) - target) ** 2).mean()
+  loss = ((image.clamp(0, 1) - target) ** 2).mean() * loss_scale
   loss.backward()
   # heuristics need the incoming image gradient
   if use_sh:
@@ -54,13 +55,13 @@ def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=Fals
               num_overlaps=out.num_overlaps)
 
 
-def hip_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, device="cuda"):
+def hip_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, device="cuda", loss_scale=1.0):
   import splat_trainer_amd as sta
   gd = sta.Gaussians3D(*(t.clone().to(device).requires_grad_(True) for t in
                          (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
   camd = cam.to(device)
   r = sta.render_gaussians(gd, camd, config, use_sh=use_sh, render_median_depth=want_median)
-  loss = ((r.image.clamp(0, 1) - target) ** 2).mean()
+  loss = ((r.image.clamp(0, 1) - target) ** 2).mean() * loss_scale
   loss.backward()
   return dict(rendering=r, image=r.image.detach(), final_T=r.final_transmittance, visibility=r.points.visibility,
               median=r.median_depth_image, depth=r.points.depths.detach(), screen_scale=r.points.screen_scale,

@@ -1,0 +1,80 @@
+"""K5 primitives on the GPU through the C ABI: exclusive scan and the stable radix sort (bit-exact)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from splat_trainer_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+  return C.c_void_p(t.data_ptr()) if t.numel() else None
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 4095, 4096, 4097, 100_000, 5_000_001])
+def test_exclusive_scan(n):
+  lib = _lib.load()
+  rng = np.random.default_rng(n)
+  x = rng.integers(0, 50, size=n, dtype=np.int64).astype(np.int32)
+  d = torch.from_numpy(x).cuda()
+  out = torch.empty_like(d)
+  total = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+  nbytes = lib.gsr_scan_workspace_bytes(n)
+  ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+  _lib.check(lib.gsr_exclusive_scan_u32(_ptr(d), _ptr(out), n, _ptr(total), _ptr(ws), nbytes, _stream()), "scan")
+  want = np.cumsum(x, dtype=np.int64) - x
+  assert np.array_equal(out.cpu().numpy(), want.astype(np.int32))
+  assert total.item() == int(x.sum())
+
+
+def _sort(keys: np.ndarray, begin_bit: int, end_bit: int, iota=True, vals=None):
+  lib = _lib.load()
+  n = keys.shape[0]
+  ka = torch.from_numpy(keys.view(np.int32)).cuda()
+  va = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
+  if not iota:
+    va[:n] = torch.from_numpy(vals.view(np.int32)).cuda()
+  kb, vb = torch.zeros_like(ka), torch.zeros_like(va)
+  nbytes = lib.gsr_sort_workspace_bytes(n)
+  ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(ka), _ptr(va), _ptr(kb), _ptr(vb), n, 1 if iota else 0, begin_bit,
+                                            end_bit, _ptr(ws), nbytes, _stream()), "sort")
+  k, v = (kb, vb) if where == 1 else (ka, va)
+  return k.cpu().numpy().view(np.uint32)[:n], v.cpu().numpy().view(np.uint32)[:n]
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 4096, 4097, 70_001, 3_000_000])
+def test_radix_sort_full_keys_is_stable(n):
+  rng = np.random.default_rng(n)
+  keys = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+  keys[rng.integers(0, n, size=n // 3)] = keys[0]          # plenty of ties
+  k, v = _sort(keys, 0, 32)
+  order = np.argsort(keys, kind="stable")
+  assert np.array_equal(k, keys[order])
+  assert np.array_equal(v, order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("bits", [1, 7, 8, 13, 15, 20])
+def test_radix_sort_partial_bits_keeps_input_order(bits):
+  n = 500_003
+  rng = np.random.default_rng(bits)
+  keys = rng.integers(0, 2 ** bits, size=n, dtype=np.uint64).astype(np.uint32)
+  vals = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+  k, v = _sort(keys, 0, bits, iota=False, vals=vals)
+  order = np.argsort(keys, kind="stable")
+  assert np.array_equal(k, keys[order])
+  assert np.array_equal(v, vals[order])
+
+
+def test_sort_rejects_bad_arguments():
+  lib = _lib.load()
+  t = torch.zeros(16, dtype=torch.int32, device="cuda")
+  assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 40, _ptr(t), 64, _stream()) == -1
+  assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 32, _ptr(t), 8, _stream()) == -2

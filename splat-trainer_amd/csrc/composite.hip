@@ -1,6 +1,8 @@
 // K6 alpha-composite forward and K7 alpha-composite backward (per-pixel reverse walk).
 //
-// Mapping: ONE wave64 owns one 16x16 tile; lane l owns the 2x2 pixel quad at (2*(l&7), 2*(l>>3)).
+// Mapping: ONE wave64 owns one 16x16 tile; lane l owns 4 pixels, one in each 8x8 quadrant of the tile, at
+//   (8*(p&1) + (l&7), 8*(p>>1) + (l>>3)), p = 0..3.  A small splat touches 1-2 quadrants, and a quadrant no lane
+//   needs is skipped by a wave-uniform branch (s_cbranch_execz), so the per-pixel work follows the footprint.
 //   * the tile's depth-sorted splat list is staged through LDS 64 records at a time (one coalesced index
 //     load + one 48-byte record gather per lane), then read back with wave-uniform (broadcast) ds_reads;
 //   * a single-wave workgroup needs no cross-wave synchronisation, and every per-splat reduction over the
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
   const int tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
   const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int px0 = tx * 16 + 2 * (lane & 7), py0 = ty * 16 + 2 * (lane >> 3);
+  const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
 
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
   for (int p = 0; p < 4; ++p) {
     T[p] = 1.f; lastc[p] = 0; med[p] = 0.f;
     col[p][0] = col[p][1] = col[p][2] = 0.f;
-    done[p] = !((px0 + (p & 1)) < W && (py0 + (p >> 1)) < H);
+    done[p] = !((px0 + 8 * (p & 1)) < W && (py0 + 8 * (p >> 1)) < H);
   }
 
   for (uint32_t base = start; base < end; base += 64) {
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         if (!done[p]) {
-          const float dx = (p & 1) ? dxa + 1.f : dxa;
-          const float dy = (p >> 1) ? dya + 1.f : dya;
+          const float dx = (p & 1) ? dxa + 8.f : dxa;
+          const float dy = (p >> 1) ? dya + 8.f : dya;
           PixelEval e = eval_pixel(dx, dy, r0.z, B2, r1.x, r1.y, rp.q_max, rp.clamp_max_alpha, rp.alpha_threshold);
           if (e.hit) {
             const float w = __fmul_rn(e.alpha, T[p]);
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
 
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int px = px0 + (p & 1), py = py0 + (p >> 1);
+    const int px = px0 + 8 * (p & 1), py = py0 + 8 * (p >> 1);
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
   const int tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
   const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int px0 = tx * 16 + 2 * (lane & 7), py0 = ty * 16 + 2 * (lane >> 3);
+  const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile];
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
   int tile_last = 0;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int px = px0 + (p & 1), py = py0 + (p >> 1);
+    const int px = px0 + 8 * (p & 1), py = py0 + 8 * (p >> 1);
     T[p] = 1.f; lastc[p] = 0;
     g[p][0] = g[p][1] = g[p][2] = 0.f;
     acc[p][0] = acc[p][1] = acc[p][2] = 0.f;
@@ -217,11 +219,11 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         if (pos < lastc[p]) {
-          const float dx = (p & 1) ? dxa + 1.f : dxa;
-          const float dy = (p >> 1) ? dya + 1.f : dya;
+          const float dx = (p & 1) ? dxa + 8.f : dxa;
+          const float dy = (p >> 1) ? dya + 8.f : dya;
           PixelEval e = eval_pixel(dx, dy, A, B2, Cc, op, rp.q_max, rp.clamp_max_alpha, rp.alpha_threshold);
           if (e.hit) {
-            const float inv = 1.f / (1.f - e.alpha);
+            const float inv = __builtin_amdgcn_rcpf(1.f - e.alpha);
             const float Tb = T[p] * inv;                    // transmittance in front of this splat
             T[p] = Tb;
             const float w = e.alpha * Tb;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
               const float gmy = GdG * (B * dx + Cc * dy);
               du += gmx;
               dv += gmy;
-              split += sqrtf(gmx * gmx + gmy * gmy);
+              split += __builtin_amdgcn_sqrtf(gmx * gmx + gmy * gmy);
             }
           }
         }

@@ -118,16 +118,18 @@ int gsr_tile_ranges(const uint32_t* sorted_keys, const uint32_t* sorted_inst, co
 
 /* ---- K6 alpha-composite forward ------------------------------------------------------------------------- */
 /* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;
- * median_depth [H,W] or NULL; vis_partial [O] (per sorted instance id) or NULL -- must be zero-filled. */
+ * median_depth [H,W] or NULL; vis_partial [O] (indexed by instance id; must be zero-filled) and pair_vis [O]
+ * (the same per-(tile,splat) visibility sum_px T*alpha, indexed by sorted list position) or both NULL. */
 int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
                           const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                           const GsrRasterParamsC* params_host, float* image_out, float* final_T_out,
-                          int32_t* last_out, float* median_depth_out, float* vis_partial_out, void* stream);
+                          int32_t* last_out, float* median_depth_out, float* vis_partial_out, float* pair_vis_out,
+                          void* stream);
 
 /* ---- K7 alpha-composite backward (per-pixel reverse walk) ----------------------------------------------- */
-/* partial_out [O,12]: written only for instances with vis_partial > 0 (the others are never read). */
+/* partial_out [O,12]: written only for pairs with pair_vis > 0 (the others are never read). */
 int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
-                           const float* vis_partial, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
+                           const float* pair_vis, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                            const GsrRasterParamsC* params_host, const float* final_T, const int32_t* last,
                            const float* dL_dimage, float* partial_out, void* stream);
 

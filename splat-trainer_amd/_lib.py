@@ -50,7 +50,7 @@ PROTOTYPES = {
     "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p]),
     "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),
     "gsr_tile_ranges": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
-    "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p]),
+    "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),

@@ -161,7 +161,7 @@ def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config
 class _RasterState:
   """Per-frame buffers shared by forward and backward (owned by the autograd node / the Rendering)."""
   __slots__ = ("M", "O", "C", "W", "H", "params", "rec", "order", "count", "offsets", "sorted_rank",
-               "sorted_inst", "tile_range", "vis_partial", "final_T", "last", "median", "visibility",
+               "sorted_inst", "tile_range", "vis_partial", "pair_vis", "final_T", "last", "median", "visibility",
                "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad")
 
 
@@ -235,13 +235,14 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
                                  _ptr(st.tile_range), _ptr(st.sorted_rank), stream), "gsr_tile_ranges")
 
   st.vis_partial = torch.zeros(O, dtype=torch.float32, device=dev) if need_vis_partial else None
+  st.pair_vis = torch.empty(O, dtype=torch.float32, device=dev) if need_vis_partial else None
   timer = KERNEL_TIMER
   if timer is not None:
     timer.begin("composite_forward")
   _lib.check(lib.gsr_composite_forward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
                                        _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
                                        _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
-                                       stream), "gsr_composite_forward")
+                                       _ptr(st.pair_vis), stream), "gsr_composite_forward")
   if timer is not None:
     timer.end("composite_forward")
   if st.compute_visibility:
@@ -275,7 +276,7 @@ class _RasterFn(torch.autograd.Function):
       if timer is not None:
         timer.begin("composite_backward")
       _lib.check(lib.gsr_composite_backward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
-                                            _ptr(st.vis_partial), _ptr(st.tile_range), st.W, st.H, st.C,
+                                            _ptr(st.pair_vis), _ptr(st.tile_range), st.W, st.H, st.C,
                                             C.byref(st.params), _ptr(st.final_T), _ptr(st.last), _ptr(dimg),
                                             _ptr(partial), stream), "gsr_composite_backward")
       if timer is not None:
@@ -309,6 +310,7 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
   st.want_median = bool(render_median_depth)
   st.compute_visibility = bool(config.compute_visibility or config.compute_point_heuristic)
   st.vis_partial = None
+  st.pair_vis = None
   st.needs_grad = torch.is_grad_enabled() and (gaussians2d.requires_grad or features.requires_grad)
   image = _RasterFn.apply(gaussians2d, features, depth, st)
   points = RenderedPoints(idx=indexes, depths=depth, opacity=gaussians2d[:, 5], screen_scale=st.screen_scale,

@@ -26,13 +26,28 @@ inline GsrRasterParams to_params(const GsrRasterParamsC* c) {
   return rp;
 }
 
-// Shared by forward and backward so both take bit-identical contribute / skip decisions: every operation is
-// an explicit round-to-nearest intrinsic, so the compiler cannot contract the two kernels differently.
-__device__ __forceinline__ float eval_q(float dx, float dy, float A, float B2, float C) {
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define GSR_V2(x) ((v2f){(x), (x)})
+
+// The VALU is the binding unit of both kernels (a wave64 fp32 op holds its SIMD for 4 cycles; only the packed
+// v_pk_{mul,add,fma}_f32 forms reach the 64 FLOP/clk/SIMD peak), so each lane evaluates its two pixels of one
+// tile half (left/right 8x8 quadrant, same row => same dy) as ONE 2-wide packed computation, branch-free, with
+// non-contributing pixels masked to alpha = 0.  A half no lane needs is skipped by a wave-uniform branch.
+//
+// eval_q2 / eval_G2 are shared by forward and backward and pin every rounding (explicit fma, contraction off), so
+// both passes take bit-identical contribute / skip decisions.
+__device__ __forceinline__ v2f eval_q2(v2f dx, float dy, float A, float B2, float C) {
+#pragma clang fp contract(off)
   // q = A dx^2 + 2B dx dy + C dy^2,   B2 = 2B
-  return __fmaf_rn(__fmul_rn(A, dx), dx, __fmaf_rn(__fmul_rn(B2, dy), dx, __fmul_rn(__fmul_rn(C, dy), dy)));
+  const float t = B2 * dy;
+  const float u = (C * dy) * dy;
+  return __builtin_elementwise_fma(dx * A, dx, __builtin_elementwise_fma(GSR_V2(t), dx, GSR_V2(u)));
 }
-__device__ __forceinline__ float eval_G(float q) { return __expf(__fmul_rn(-0.5f, q)); }
+__device__ __forceinline__ v2f eval_G2(v2f q) {     // exp(-q/2) = 2^(q * -0.5*log2(e))
+#pragma clang fp contract(off)
+  const v2f e = q * -0.72134752044448170368f;
+  return (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+}
 
 struct Splat {            // one depth-ordered record, wave-uniform (lives in SGPRs)
   float u, v, A, B, C, op, depth, f0, f1, f2;
@@ -69,13 +84,18 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
 
-  float T[4], col[4][3], med[4];
+  // pixel p = 2h + i : half h (rows py0 + 8h), side i (cols px0 + 8i); packed over i
+  v2f T2[2], col2[2][3], med2[2];
   int lastc[4];
   bool done[4];
 #pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    T2[h] = GSR_V2(1.f); med2[h] = GSR_V2(0.f);
+    col2[h][0] = col2[h][1] = col2[h][2] = GSR_V2(0.f);
+  }
+#pragma unroll
   for (int p = 0; p < 4; ++p) {
-    T[p] = 1.f; lastc[p] = 0; med[p] = 0.f;
-    col[p][0] = col[p][1] = col[p][2] = 0.f;
+    lastc[p] = 0;
     done[p] = !((px0 + 8 * (p & 1)) < W && (py0 + 8 * (p >> 1)) < H);
   }
 
@@ -88,30 +108,41 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
       const Splat s = nxt;
       if (j + 1 < n) nxt = load_splat<C>(rec, sorted_rank, base + j + 1);     // prefetch (scalar loads)
       const float dxa = fx0 - s.u, dya = fy0 - s.v;
+      const v2f dx2 = {dxa, dxa + 8.f};
       const float B2 = s.B + s.B;
-      float wsum = 0.f;
+      const int idx = (int)(base - start + j) + 1;
+      v2f wsum2 = GSR_V2(0.f);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float dx = (p & 1) ? dxa + 8.f : dxa;
-        const float dy = (p >> 1) ? dya + 8.f : dya;
-        const float q = eval_q(dx, dy, s.A, B2, s.C);
-        if (!done[p] && q <= rp.q_max) {
-          const float a_raw = __fmul_rn(s.op, eval_G(q));
-          const float alpha = fminf(rp.clamp_max_alpha, a_raw);
-          if (alpha >= rp.alpha_threshold) {
-            const float w = __fmul_rn(alpha, T[p]);
-            col[p][0] = __fmaf_rn(w, s.f0, col[p][0]);
-            if (C > 1) col[p][1] = __fmaf_rn(w, s.f1, col[p][1]);
-            if (C > 2) col[p][2] = __fmaf_rn(w, s.f2, col[p][2]);
-            wsum += w;
-            T[p] = __fmul_rn(T[p], 1.f - alpha);
-            lastc[p] = (int)(base - start + j) + 1;
-            if (MEDIAN && med[p] == 0.f && T[p] < 0.5f) med[p] = s.depth;
-            if (T[p] < rp.T_eps) done[p] = true;
+      for (int h = 0; h < 2; ++h) {
+        const float dy = h ? dya + 8.f : dya;
+        const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+        const bool in0 = !done[2 * h] && q.x <= rp.q_max;
+        const bool in1 = !done[2 * h + 1] && q.y <= rp.q_max;
+        if (__ballot(in0 || in1) != 0ull) {
+          const v2f G = eval_G2(q);
+          const v2f a_raw = G * s.op;
+          v2f alpha = __builtin_elementwise_min(a_raw, GSR_V2(rp.clamp_max_alpha));
+          const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
+          const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
+          alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
+          const v2f w = alpha * T2[h];
+          col2[h][0] = __builtin_elementwise_fma(w, GSR_V2(s.f0), col2[h][0]);
+          if (C > 1) col2[h][1] = __builtin_elementwise_fma(w, GSR_V2(s.f1), col2[h][1]);
+          if (C > 2) col2[h][2] = __builtin_elementwise_fma(w, GSR_V2(s.f2), col2[h][2]);
+          wsum2 += w;
+          T2[h] = T2[h] * (GSR_V2(1.f) - alpha);
+          if (hit0) lastc[2 * h] = idx;
+          if (hit1) lastc[2 * h + 1] = idx;
+          if (MEDIAN) {
+            if (hit0 && med2[h].x == 0.f && T2[h].x < 0.5f) med2[h].x = s.depth;
+            if (hit1 && med2[h].y == 0.f && T2[h].y < 0.5f) med2[h].y = s.depth;
           }
+          if (hit0 && T2[h].x < rp.T_eps) done[2 * h] = true;
+          if (hit1 && T2[h].y < rp.T_eps) done[2 * h + 1] = true;
         }
       }
       if (VIS) {
+        const float wsum = wsum2.x + wsum2.y;
         if (__ballot(wsum > 0.f) != 0ull) {
           const float tot = gsr_wave_sum(wsum);
           if ((uint32_t)lane == j) my_vis = tot;
@@ -131,11 +162,12 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
     const int px = px0 + 8 * (p & 1), py = py0 + 8 * (p >> 1);
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
+      const int h = p >> 1;
 #pragma unroll
-      for (int c = 0; c < C; ++c) image[pix * C + c] = col[p][c];
-      final_T[pix] = T[p];
+      for (int c = 0; c < C; ++c) image[pix * C + c] = (p & 1) ? col2[h][c].y : col2[h][c].x;
+      final_T[pix] = (p & 1) ? T2[h].y : T2[h].x;
       last[pix] = lastc[p];
-      if (MEDIAN) median[pix] = med[p];
+      if (MEDIAN) median[pix] = (p & 1) ? med2[h].y : med2[h].x;
     }
   }
 }
@@ -158,21 +190,31 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile];
 
-  // per pixel: T behind the current splat, g = dL/dC, ga = g . (colour accumulated behind the current splat)
-  float T[4], g[4][3], ga[4];
+  // per pixel (packed over the two sides of a half): T behind the current splat, g = dL/dC,
+  // ga = g . (colour accumulated behind the current splat)
+  v2f T2[2], g2[2][3], ga2[2];
   int lastc[4];
   int tile_last = 0;
 #pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    T2[h] = GSR_V2(1.f); ga2[h] = GSR_V2(0.f);
+    g2[h][0] = g2[h][1] = g2[h][2] = GSR_V2(0.f);
+  }
+#pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int px = px0 + 8 * (p & 1), py = py0 + 8 * (p >> 1);
-    T[p] = 1.f; lastc[p] = 0; ga[p] = 0.f;
-    g[p][0] = g[p][1] = g[p][2] = 0.f;
+    const int h = p >> 1;
+    lastc[p] = 0;
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
-      T[p] = final_T[pix];
+      const float t = final_T[pix];
+      if (p & 1) T2[h].y = t; else T2[h].x = t;
       lastc[p] = last[pix];
 #pragma unroll
-      for (int c = 0; c < C; ++c) g[p][c] = dL_dimage[pix * C + c];
+      for (int c = 0; c < C; ++c) {
+        const float gv = dL_dimage[pix * C + c];
+        if (p & 1) g2[h][c].y = gv; else g2[h][c].x = gv;
+      }
     }
     tile_last = max(tile_last, lastc[p]);
   }
@@ -180,6 +222,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
   for (int o = 32; o > 0; o >>= 1) tile_last = max(tile_last, __shfl_xor(tile_last, o, 64));
   tile_last = __builtin_amdgcn_readfirstlane(tile_last);
   if (tile_last == 0) return;
+  const int slot_of_row = ((lane >> 4) & 1) * 2 + (lane >> 5);      // {0,2,1,3}[lane >> 4]
 
   for (int cbase = ((tile_last - 1) >> 6) << 6; cbase >= 0; cbase -= 64) {
     const int n = min(64, tile_last - cbase);
@@ -202,57 +245,70 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
         inst_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorted_inst[start + (uint32_t)(cbase + j)]);
       }
       const float dxa = fx0 - s.u, dya = fy0 - s.v;
+      const v2f dx2 = {dxa, dxa + 8.f};
       const float B2 = s.B + s.B;
-      float du = 0.f, dv = 0.f, dA = 0.f, dB = 0.f, dC = 0.f, dop = 0.f, prune = 0.f, split = 0.f;
-      float df[3] = {0.f, 0.f, 0.f};
+      v2f du2 = GSR_V2(0.f), dv2 = du2, dA2 = du2, dB2 = du2, dC2 = du2, dop2 = du2, prune2 = du2, split2 = du2;
+      v2f df2[3] = {du2, du2, du2};
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float dx = (p & 1) ? dxa + 8.f : dxa;
-        const float dy = (p >> 1) ? dya + 8.f : dya;
-        const float q = eval_q(dx, dy, s.A, B2, s.C);
-        if (pos < lastc[p] && q <= rp.q_max) {
-          const float G = eval_G(q);
-          const float a_raw = __fmul_rn(s.op, G);
-          const float alpha = fminf(rp.clamp_max_alpha, a_raw);
-          if (alpha >= rp.alpha_threshold) {
-            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-            const float Tb = T[p] * inv;                    // transmittance in front of this splat
-            T[p] = Tb;
-            const float w = alpha * Tb;
-            float gc = g[p][0] * s.f0;
-            if (C > 1) gc += g[p][1] * s.f1;
-            if (C > 2) gc += g[p][2] * s.f2;
-            df[0] += w * g[p][0];
-            if (C > 1) df[1] += w * g[p][1];
-            if (C > 2) df[2] += w * g[p][2];
-            const float dLda = Tb * gc - ga[p] * inv;       // dC/dalpha = T c - (colour behind)/(1-alpha)
-            ga[p] += gc * w;
-            prune += fabsf(dLda) * alpha;
-            if (a_raw <= rp.clamp_max_alpha) {
-              dop += dLda * G;
-              const float GdG = G * dLda * s.op;            // G * dL/dG
-              const float dq = -0.5f * GdG;
-              dA += dq * dx * dx;
-              dB += dq * 2.f * dx * dy;
-              dC += dq * dy * dy;
-              const float gmx = GdG * (s.A * dx + s.B * dy);
-              const float gmy = GdG * (s.B * dx + s.C * dy);
-              du += gmx;
-              dv += gmy;
-              split += __builtin_amdgcn_sqrtf(gmx * gmx + gmy * gmy);
-            }
-          }
+      for (int h = 0; h < 2; ++h) {
+        const float dy = h ? dya + 8.f : dya;
+        const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+        const bool in0 = pos < lastc[2 * h] && q.x <= rp.q_max;
+        const bool in1 = pos < lastc[2 * h + 1] && q.y <= rp.q_max;
+        if (__ballot(in0 || in1) != 0ull) {
+          const v2f G = eval_G2(q);
+          const v2f a_raw = G * s.op;
+          v2f alpha = __builtin_elementwise_min(a_raw, GSR_V2(rp.clamp_max_alpha));
+          const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
+          const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
+          alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
+          const v2f om = GSR_V2(1.f) - alpha;
+          const v2f inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};   // rcp(1) == 1 exactly
+          const v2f Tb = T2[h] * inv;                        // transmittance in front of this splat
+          T2[h] = Tb;
+          const v2f w = alpha * Tb;
+          v2f gc = g2[h][0] * s.f0;
+          if (C > 1) gc = __builtin_elementwise_fma(g2[h][1], GSR_V2(s.f1), gc);
+          if (C > 2) gc = __builtin_elementwise_fma(g2[h][2], GSR_V2(s.f2), gc);
+          df2[0] = __builtin_elementwise_fma(w, g2[h][0], df2[0]);
+          if (C > 1) df2[1] = __builtin_elementwise_fma(w, g2[h][1], df2[1]);
+          if (C > 2) df2[2] = __builtin_elementwise_fma(w, g2[h][2], df2[2]);
+          const v2f dLda = Tb * gc - ga2[h] * inv;           // dC/dalpha = T c - (colour behind)/(1-alpha)
+          ga2[h] = __builtin_elementwise_fma(gc, w, ga2[h]);
+          prune2 = __builtin_elementwise_fma(__builtin_elementwise_abs(dLda), alpha, prune2);
+          // gradient through G = exp(-q/2) only where the pixel contributed and the alpha clamp is inactive
+          const bool m0 = hit0 && a_raw.x <= rp.clamp_max_alpha;
+          const bool m1 = hit1 && a_raw.y <= rp.clamp_max_alpha;
+          v2f GdL = G * dLda;
+          GdL = (v2f){m0 ? GdL.x : 0.f, m1 ? GdL.y : 0.f};
+          dop2 += GdL;
+          const v2f GdG = GdL * s.op;                        // G * dL/dG
+          const v2f dq = GdG * -0.5f;
+          const v2f dqdx = dq * dx2;
+          dA2 = __builtin_elementwise_fma(dqdx, dx2, dA2);
+          dB2 = __builtin_elementwise_fma(dqdx, GSR_V2(2.f * dy), dB2);
+          dC2 = __builtin_elementwise_fma(dq, GSR_V2(dy * dy), dC2);
+          const v2f tx_ = __builtin_elementwise_fma(dx2, GSR_V2(s.A), GSR_V2(s.B * dy));
+          const v2f ty_ = __builtin_elementwise_fma(dx2, GSR_V2(s.B), GSR_V2(s.C * dy));
+          const v2f gmx = GdG * tx_, gmy = GdG * ty_;
+          du2 += gmx;
+          dv2 += gmy;
+          const v2f nn = __builtin_elementwise_fma(gmx, gmx, gmy * gmy);
+          split2 += (v2f){__builtin_amdgcn_sqrtf(nn.x), __builtin_amdgcn_sqrtf(nn.y)};
         }
       }
-      // fixed-order fused-DPP wave reductions; totals land in lane 63, which owns the store
-      if (C == 1) gsr_wave_sum9_to_lane63(du, dv, dA, dB, dC, dop, prune, split, df[0]);
-      else if (C == 2) gsr_wave_sum10_to_lane63(du, dv, dA, dB, dC, dop, prune, split, df[0], df[1]);
-      else gsr_wave_sum11_to_lane63(du, dv, dA, dB, dC, dop, prune, split, df[0], df[1], df[2]);
-      if (lane == 63) {
-        float4* out = reinterpret_cast<float4*>(partial + (size_t)GSR_PARTIAL_FLOATS * inst_j);
-        out[0] = make_float4(du, dv, dA, dB);
-        out[1] = make_float4(dC, dop, prune, split);
-        out[2] = make_float4(df[0], df[1], df[2], 0.f);
+      float du = du2.x + du2.y, dv = dv2.x + dv2.y, dA = dA2.x + dA2.y, dB = dB2.x + dB2.y, dC = dC2.x + dC2.y;
+      float dop = dop2.x + dop2.y, prune = prune2.x + prune2.y, split = split2.x + split2.y;
+      float df[3] = {df2[0].x + df2[0].y, df2[1].x + df2[1].y, df2[2].x + df2[2].y};
+      // fixed-order transposing wave reduction: lane 16r+15 of tj ends with the total of slot 4j + {0,2,1,3}[r]
+      const float vals[12] = {du, dv, dA, dB, dC, dop, prune, split, df[0], df[1], df[2], 0.f};
+      float t0, t1, t2;
+      gsr_wave_sum12_transposed(vals, t0, t1, t2);
+      if ((lane & 15) == 15) {
+        float* out = partial + (size_t)GSR_PARTIAL_FLOATS * inst_j + slot_of_row;
+        out[0] = t0;
+        out[4] = t1;
+        out[8] = t2;
       }
       if (!more) break;
     }

@@ -62,12 +62,16 @@ def make_workload(name: str, world: int):
   return g, cams, w
 
 
-def cpu_baseline(g, cam, cfg, sample_tiles: int = 96):
+def cpu_baseline(g, cam, cfg, sample_tiles: int = 640):
   """The CPU PyTorch path (oracle, autograd) on the host cores, on a bounded sample of the same workload:
   cull + projection + SH for ALL Gaussians (forward and backward), composite forward+backward on
   ``sample_tiles`` of the image's tiles; the tile part is extrapolated to the full image."""
   from oracle import torch_oracle as oracle        # checker / baseline only
-  cores = os.cpu_count() or 1
+  try:
+    cores = len(os.sched_getaffinity(0))
+  except AttributeError:
+    cores = os.cpu_count() or 1
+  cores = max(1, min(cores, 16))          # the GPU box grants a 16-CPU share per GPU; more threads only thrash
   torch.set_num_threads(cores)
   W, H = cam.image_size
   tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
@@ -139,13 +143,17 @@ def main():
   target = 0.5
   scene = sta.Gaussians3D(position=position, rotation=rotation, log_scaling=log_scaling, alpha_logit=alpha_logit,
                           feature=feature)
+  # gradients accumulate straight into the flat collective buffer (the reference accumulates into .grad over
+  # the cameras of a batch, trainer.py:500-514)
+  grad_out = sta.GradOut(position=bucket.views[0], log_scaling=bucket.views[1], rotation=bucket.views[2],
+                         alpha_logit=bucket.views[3], feature=bucket.views[4])
   last = {}
 
   def step():
     bucket.zero()
     for cam in my_cams:
       with torch.enable_grad():
-        r = sta.render_gaussians(scene, cam, cfg, use_sh=True)
+        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out)
         loss = ((r.image.clamp(0, 1) - target) ** 2).mean()
         loss.backward()
       bucket.extra.index_add_(0, r.points.idx, r.points.visibility)

@@ -55,7 +55,7 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 2) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -82,22 +82,24 @@ int gsr_project_forward(const float* position, const float* log_scaling, const f
                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                         const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
                         float* depth_out, void* stream);
-/* Writes rows ``indexes`` of the N-sized gradient tensors (rows not listed are left untouched: pass zeros). */
+/* Rows ``indexes`` of the N-sized gradient tensors are written (accumulate = 0: other rows untouched, pass
+ * zeros) or added to (accumulate = 1: "+=" straight into the caller's .grad buffers; rows are unique, no atomics). */
 int gsr_project_backward(const float* position, const float* log_scaling, const float* rotation_xyzw,
                          const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                          const float* projection, const GsrRasterParamsC* params_host, const float* dL_dgaussians2d,
                          const float* dL_ddepth, float* d_position, float* d_log_scaling, float* d_rotation,
-                         float* d_alpha_logit, void* stream);
+                         float* d_alpha_logit, int32_t accumulate, void* stream);
 
 /* ---- K3 spherical-harmonics colour forward / backward  (evaluate_sh_at) --------------------------------- */
 /* sh_features [N,3,K], K in {1,4,9,16}; colour = 0.5 + sum_k sh[c][k] Y_k(normalize(p - camera_pos)). */
 int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
                    const float* camera_pos, float* colors_out, void* stream);
-/* d_sh_features [N,3,K] and d_positions [N,3] (may be NULL): rows ``indexes`` are written, pass zeros.
+/* d_sh_features [N,3,K] and d_positions [N,3] (may be NULL): rows ``indexes`` are written (accumulate = 0, pass
+ * zeros) or added to (accumulate = 1).
  * d_positions is the gradient through the view direction normalize(p - camera_pos). */
 int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const float* positions, const int64_t* indexes,
                     int64_t M, int32_t K, const float* camera_pos, float* d_sh_features, float* d_positions,
-                    void* stream);
+                    int32_t accumulate, void* stream);
 
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */
 /* depth -> sortable u32 keys */

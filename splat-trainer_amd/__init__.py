@@ -5,10 +5,10 @@ Import as ``splat_trainer_amd`` (the repo-root shim ``splat_trainer_amd.py`` loa
 whose name carries a hyphen)."""
 from .data_types import (CameraParams, Gaussians3D, RasterConfig, RenderedPoints, Rendering,
                          pop_raster_config)
-from .renderer import frustum_cull, project_to_image, render_gaussians, render_projected
+from .renderer import GradOut, frustum_cull, project_to_image, render_gaussians, render_projected
 from .sh import evaluate_sh_at
 from ._lib import GsplatHipError
 
 __all__ = ["CameraParams", "Gaussians3D", "RasterConfig", "RenderedPoints", "Rendering", "pop_raster_config",
            "frustum_cull", "project_to_image", "render_projected", "render_gaussians", "evaluate_sh_at",
-           "GsplatHipError"]
+           "GsplatHipError", "GradOut"]

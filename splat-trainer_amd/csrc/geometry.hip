@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const float* __restric
   depth[m] = o.depth;
 }
 
+template <bool ACC>
 __global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ ls,
                                                           const float* __restrict__ rot, const float* __restrict__ logit,
                                                           const int64_t* __restrict__ idx, int64_t M,
@@ -97,13 +98,19 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restric
   for (int k = 0; k < 6; ++k) g[k] = dg2d[6 * m + k];
   const float gd = ddepth ? ddepth[m] : 0.f;
   GsrProjectGrad o = gsr_project_one_bwd(cam, rp, p, s, q, logit[i], g, gd);
+  // rows of ``idx`` are unique, so the accumulate form (+=) is a race-free read-modify-write
+  float4 r = make_float4(o.dq[0], o.dq[1], o.dq[2], o.dq[3]);
+  if (ACC) {
+    const float4 old = *reinterpret_cast<const float4*>(drot + 4 * i);
+    r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    dpos[3 * i + k] = o.dp[k];
-    dls[3 * i + k] = o.dls[k];
+    dpos[3 * i + k] = ACC ? dpos[3 * i + k] + o.dp[k] : o.dp[k];
+    dls[3 * i + k] = ACC ? dls[3 * i + k] + o.dls[k] : o.dls[k];
   }
-  *reinterpret_cast<float4*>(drot + 4 * i) = make_float4(o.dq[0], o.dq[1], o.dq[2], o.dq[3]);
-  dlogit[i] = o.dlogit;
+  *reinterpret_cast<float4*>(drot + 4 * i) = r;
+  dlogit[i] = ACC ? dlogit[i] + o.dlogit : o.dlogit;
 }
 
 template <int K>
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
   out[3 * m] = c[0]; out[3 * m + 1] = c[1]; out[3 * m + 2] = c[2];
 }
 
-template <int K>
+template <int K, bool ACC>
 __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ dcol, const float* __restrict__ sh,
                                                      const float* __restrict__ pos, const int64_t* __restrict__ idx,
                                                      int64_t M, const float* __restrict__ cam_pos,
@@ -157,11 +164,17 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ d
     const float g = g3[ch];
     if (K % 4 == 0) {
 #pragma unroll
-      for (int k = 0; k < K; k += 4)
-        *reinterpret_cast<float4*>(row + ch * K + k) = make_float4(g * Y[k], g * Y[k + 1], g * Y[k + 2], g * Y[k + 3]);
+      for (int k = 0; k < K; k += 4) {
+        float4 v = make_float4(g * Y[k], g * Y[k + 1], g * Y[k + 2], g * Y[k + 3]);
+        if (ACC) {
+          const float4 old = *reinterpret_cast<const float4*>(row + ch * K + k);
+          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        }
+        *reinterpret_cast<float4*>(row + ch * K + k) = v;
+      }
     } else {
 #pragma unroll
-      for (int k = 0; k < K; ++k) row[ch * K + k] = g * Y[k];
+      for (int k = 0; k < K; ++k) row[ch * K + k] = ACC ? row[ch * K + k] + g * Y[k] : g * Y[k];
     }
   }
   if (dpos != nullptr && K > 1) {
@@ -179,9 +192,10 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ d
       }
     }
     const float dot = gx * x + gy * y + gz * z;
-    dpos[3 * i] = (gx - x * dot) * inv;
-    dpos[3 * i + 1] = (gy - y * dot) * inv;
-    dpos[3 * i + 2] = (gz - z * dot) * inv;
+    const float px_ = (gx - x * dot) * inv, py_ = (gy - y * dot) * inv, pz_ = (gz - z * dot) * inv;
+    dpos[3 * i] = ACC ? dpos[3 * i] + px_ : px_;
+    dpos[3 * i + 1] = ACC ? dpos[3 * i + 1] + py_ : py_;
+    dpos[3 * i + 2] = ACC ? dpos[3 * i + 2] + pz_ : pz_;
   }
 }
 
@@ -197,7 +211,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 1; }
+int gsr_abi_version(void) { return 2; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -262,17 +276,23 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
                          const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                          const float* projection, const GsrRasterParamsC* params_host, const float* dL_dgaussians2d,
                          const float* dL_ddepth, float* d_position, float* d_log_scaling, float* d_rotation,
-                         float* d_alpha_logit, void* stream_) {
+                         float* d_alpha_logit, int32_t accumulate, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
   if (!position || !log_scaling || !rotation_xyzw || !alpha_logit || !indexes || !T_camera_world || !projection ||
       !dL_dgaussians2d || !d_position || !d_log_scaling || !d_rotation || !d_alpha_logit)
     return GSR_ERR_INVALID_ARGUMENT;
-  project_bwd_kernel<<<grid_for(M, 256), 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
-                                                          T_camera_world, projection, to_params(params_host),
-                                                          dL_dgaussians2d, dL_ddepth, d_position, d_log_scaling,
-                                                          d_rotation, d_alpha_logit);
+  if (accumulate)
+    project_bwd_kernel<true><<<grid_for(M, 256), 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit,
+                                                                  indexes, M, T_camera_world, projection,
+                                                                  to_params(params_host), dL_dgaussians2d, dL_ddepth,
+                                                                  d_position, d_log_scaling, d_rotation, d_alpha_logit);
+  else
+    project_bwd_kernel<false><<<grid_for(M, 256), 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit,
+                                                                   indexes, M, T_camera_world, projection,
+                                                                   to_params(params_host), dL_dgaussians2d, dL_ddepth,
+                                                                   d_position, d_log_scaling, d_rotation, d_alpha_logit);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
@@ -297,7 +317,7 @@ int gsr_sh_forward(const float* sh_features, const float* positions, const int64
 
 int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const float* positions, const int64_t* indexes,
                     int64_t M, int32_t K, const float* camera_pos, float* d_sh_features, float* d_positions,
-                    void* stream_) {
+                    int32_t accumulate, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
@@ -306,10 +326,22 @@ int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const flo
     return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
   switch (K) {
-    case 1: sh_bwd_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
-    case 4: sh_bwd_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
-    case 9: sh_bwd_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
-    default: sh_bwd_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions); break;
+    case 1:
+      if (accumulate) sh_bwd_kernel<1, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      else sh_bwd_kernel<1, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      break;
+    case 4:
+      if (accumulate) sh_bwd_kernel<4, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      else sh_bwd_kernel<4, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      break;
+    case 9:
+      if (accumulate) sh_bwd_kernel<9, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      else sh_bwd_kernel<9, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      break;
+    default:
+      if (accumulate) sh_bwd_kernel<16, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      else sh_bwd_kernel<16, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      break;
   }
   GSR_CHECK_LAUNCH();
   return GSR_OK;

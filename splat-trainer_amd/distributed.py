@@ -34,17 +34,17 @@ class GradBucket:
     self.params = list(params)
     self.world_size = max(world_size, 1)
     sizes = [p.numel() for p in self.params]
-    total = sum(sizes) + extra
+    align = 64                                        # floats: every view starts on a 256-byte boundary (the
+    starts, off = [], 0                               # kernels use 16-byte vector accesses on gradient rows)
+    for n in sizes + [extra]:
+      starts.append(off)
+      off += ((n + align - 1) // align) * align
+    total = off
     self.padded = ((total + self.world_size - 1) // self.world_size) * self.world_size
     dev = self.params[0].device
     self.flat = torch.zeros(self.padded, dtype=torch.float32, device=dev)
-    self.views = []
-    off = 0
-    for p, n in zip(self.params, sizes):
-      v = self.flat[off:off + n].view_as(p)
-      self.views.append(v)
-      off += n
-    self.extra = self.flat[off:off + extra]          # e.g. the per-point `visible` accumulator
+    self.views = [self.flat[o:o + n].view_as(p) for p, n, o in zip(self.params, sizes, starts)]
+    self.extra = self.flat[starts[-1]:starts[-1] + extra]   # e.g. the per-point `visible` accumulator
     self.attach()
 
   def attach(self):

@@ -97,7 +97,7 @@ def frustum_cull(position: torch.Tensor, camera_params: CameraParams, config: Ra
   T = _f32c(camera_params.T_camera_world)
   proj = _f32c(camera_params.projection)
   indexes = torch.empty(N, dtype=torch.int64, device=dev)
-  count = torch.zeros(1, dtype=torch.int32, device=dev)
+  count = torch.empty(1, dtype=torch.int32, device=dev)
   ws_bytes = lib.gsr_cull_workspace_bytes(N)
   ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
   _lib.check(lib.gsr_frustum_cull(_ptr(pos), N, _ptr(T), _ptr(proj), int(W), int(H),
@@ -108,9 +108,27 @@ def frustum_cull(position: torch.Tensor, camera_params: CameraParams, config: Ra
   return indexes[:M]
 
 
+class GradOut:
+  """Optional fused gradient accumulation.  When given to project_to_image / evaluate_sh_at / render_gaussians,
+  the backward kernels add ("+=") their rows straight into these N-sized buffers -- typically the parameters'
+  ``.grad`` tensors, which is where the reference accumulates over the cameras of a batch
+  (trainer.py:500-514, mlp_scene.py:155-161) -- and autograd receives no gradient for those inputs.  This
+  removes the zero-fill + dense add of N-sized temporaries per camera.  Default (None): plain autograd."""
+
+  def __init__(self, position=None, log_scaling=None, rotation=None, alpha_logit=None, feature=None):
+    self.position, self.log_scaling, self.rotation = position, log_scaling, rotation
+    self.alpha_logit, self.feature = alpha_logit, feature
+
+  def _check(self, name, like):
+    t = getattr(self, name)
+    if t is None or t.shape != like.shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != like.device:
+      raise ValueError(f"GradOut.{name} must be a contiguous float32 tensor shaped like the parameter")
+    return t
+
+
 class _ProjectFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, position, log_scaling, rotation, alpha_logit, indexes, T, proj, params):
+  def forward(ctx, position, log_scaling, rotation, alpha_logit, indexes, T, proj, params, grad_out):
     lib = _lib.load()
     pos, ls, rot, al = _f32c(position), _f32c(log_scaling), _f32c(rotation), _f32c(alpha_logit)
     M = indexes.shape[0]
@@ -121,29 +139,35 @@ class _ProjectFn(torch.autograd.Function):
                "gsr_project_forward")
     ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
     ctx.params = params
+    ctx.grad_out = grad_out
     return g2d, depth
 
   @staticmethod
   def backward(ctx, d_g2d, d_depth):
     lib = _lib.load()
     pos, ls, rot, al, indexes, T, proj = ctx.saved_tensors
-    M = indexes.shape[0]
-    d_pos = torch.zeros_like(pos)
-    d_ls = torch.zeros_like(ls)
-    d_rot = torch.zeros_like(rot)
-    d_al = torch.zeros_like(al)
+    M, N = indexes.shape[0], pos.shape[0]
+    go = ctx.grad_out
+    if go is not None:
+      d_pos, d_ls = go._check("position", pos), go._check("log_scaling", ls)
+      d_rot, d_al = go._check("rotation", rot), go._check("alpha_logit", al)
+    else:
+      alloc = torch.empty_like if M == N else torch.zeros_like      # every row is written when nothing was culled
+      d_pos, d_ls, d_rot, d_al = alloc(pos), alloc(ls), alloc(rot), alloc(al)
     if M > 0:
       dg = _f32c(d_g2d) if d_g2d is not None else torch.zeros(M, 6, dtype=torch.float32, device=pos.device)
       dd = _f32c(d_depth) if d_depth is not None else None
       _lib.check(lib.gsr_project_backward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M, _ptr(T),
                                           _ptr(proj), C.byref(ctx.params), _ptr(dg), _ptr(dd), _ptr(d_pos),
-                                          _ptr(d_ls), _ptr(d_rot), _ptr(d_al), _stream()),
-                 "gsr_project_backward")
-    return d_pos, d_ls, d_rot, d_al, None, None, None, None
+                                          _ptr(d_ls), _ptr(d_rot), _ptr(d_al), 1 if go is not None else 0,
+                                          _stream()), "gsr_project_backward")
+    if go is not None:
+      return None, None, None, None, None, None, None, None, None
+    return d_pos, d_ls, d_rot, d_al, None, None, None, None, None
 
 
-def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig
-                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
+                     grad_out: Optional[GradOut] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
   """K1 cull + K2 projection.  Returns ``gaussians2d (M,6) = [u v A B C opacity]``, ``depth (M,1)``,
   ``indexes (M,) int64`` (ascending).  Differentiable wrt position / log_scaling / rotation /
   alpha_logit; gradients land in N-sized tensors, zero outside ``indexes``."""
@@ -153,7 +177,7 @@ def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config
   proj = _f32c(camera_params.projection)
   params = _lib.raster_params(config)
   g2d, depth = _ProjectFn.apply(gaussians.position, gaussians.log_scaling, gaussians.rotation,
-                                gaussians.alpha_logit, indexes, T, proj, params)
+                                gaussians.alpha_logit, indexes, T, proj, params, grad_out)
   return g2d, depth, indexes
 
 
@@ -177,17 +201,21 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   stream = _stream()
   tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
   num_tiles = tiles_x * tiles_y
-  image = torch.zeros(H, W, C_, dtype=torch.float32, device=dev)
-  st.final_T = torch.ones(H, W, dtype=torch.float32, device=dev)
-  st.last = torch.zeros(H, W, dtype=torch.int32, device=dev)
-  st.median = torch.zeros(H, W, dtype=torch.float32, device=dev) if st.want_median else None
-  st.visibility = torch.zeros(M, dtype=torch.float32, device=dev)
-  st.prune_cost = torch.zeros(M, dtype=torch.float32, device=dev)
-  st.split_score = torch.zeros(M, dtype=torch.float32, device=dev)
-  st.screen_scale = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+  heur = torch.zeros(2, M, dtype=torch.float32, device=dev)     # zero until backward fills them in place
+  st.prune_cost, st.split_score = heur[0], heur[1]
   st.O = 0
+
+  def blank():
+    st.final_T = torch.ones(H, W, dtype=torch.float32, device=dev)
+    st.last = torch.zeros(H, W, dtype=torch.int32, device=dev)
+    st.median = torch.zeros(H, W, dtype=torch.float32, device=dev) if st.want_median else None
+    st.visibility = torch.zeros(M, dtype=torch.float32, device=dev)
+    return torch.zeros(H, W, C_, dtype=torch.float32, device=dev)
+
   if M == 0:
-    return image
+    st.screen_scale = torch.zeros(0, 2, dtype=torch.float32, device=dev)
+    return blank()
+  st.screen_scale = torch.empty(M, 2, dtype=torch.float32, device=dev)   # written for every splat by K4
 
   # depth order of the M splats (stable: ties keep ascending index)
   keys_a, keys_b, vals_a, vals_b = _u32(M, dev), _u32(M, dev), _u32(M, dev), _u32(M, dev)
@@ -202,7 +230,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
   st.count = _u32(M, dev)
   st.offsets = _u32(M, dev)
-  total = torch.zeros(1, dtype=torch.int32, device=dev)
+  total = torch.empty(1, dtype=torch.int32, device=dev)
   _lib.check(lib.gsr_tile_count(_ptr(g2d), _ptr(depth), _ptr(feats), _ptr(st.order), M, C_, W, H,
                                 C.byref(st.params), _ptr(st.rec), _ptr(st.count), _ptr(st.screen_scale), stream),
              "gsr_tile_count")
@@ -215,7 +243,13 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     raise _lib.GsplatHipError("tile overlap count overflowed 2^31")
   st.O = O
   if O == 0:
-    return image
+    return blank()
+  # K6 writes every pixel of every tile (an empty tile writes colour 0, T 1, last 0): no zero-fills needed
+  image = torch.empty(H, W, C_, dtype=torch.float32, device=dev)
+  st.final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
+  st.last = torch.empty(H, W, dtype=torch.int32, device=dev)
+  st.median = torch.empty(H, W, dtype=torch.float32, device=dev) if st.want_median else None
+  st.visibility = (torch.empty if st.compute_visibility else torch.zeros)(M, dtype=torch.float32, device=dev)
 
   # emit (tile id, instance) in depth order, stable-sort by tile id, find per-tile ranges
   tkeys_a, tkeys_b, tvals_a, tvals_b = _u32(O, dev), _u32(O, dev), _u32(O, dev), _u32(O, dev)
@@ -264,9 +298,11 @@ class _RasterFn(torch.autograd.Function):
     lib = _lib.load()
     st: _RasterState = ctx.st
     dev = d_image.device
-    d_g2d = torch.zeros(st.M, 6, dtype=torch.float32, device=dev)
-    d_feat = torch.zeros(st.M, st.C, dtype=torch.float32, device=dev)
-    if st.M > 0 and st.O > 0:
+    live = st.M > 0 and st.O > 0
+    alloc = torch.empty if live else torch.zeros                # the per-splat reduction writes every row
+    d_g2d = alloc(st.M, 6, dtype=torch.float32, device=dev)
+    d_feat = alloc(st.M, st.C, dtype=torch.float32, device=dev)
+    if live:
       if st.vis_partial is None:
         raise _lib.GsplatHipError("backward called on a rendering made without gradient state")
       stream = _stream()
@@ -320,15 +356,22 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
 
 
 def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config: Optional[RasterConfig] = None,
-                     use_sh: bool = False, render_median_depth: bool = False, **options) -> Rendering:
+                     use_sh: bool = False, render_median_depth: bool = False, grad_out: Optional[GradOut] = None,
+                     **options) -> Rendering:
   """One-call form (splat_trainer/scripts/test_split.py:30): project -> colour -> rasterize.
   ``use_sh``: ``gaussians.feature`` is (N, 3, K) SH coefficients evaluated towards the camera;
   otherwise it is an (N, C) per-point colour."""
   config = config or RasterConfig()
-  g2d, depth, indexes = project_to_image(gaussians, camera_params, config)
+  g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out)
   if use_sh:
-    feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_params.camera_position)
+    sh_out = None
+    if grad_out is not None:
+      sh_out = (grad_out._check("feature", gaussians.feature), grad_out._check("position", gaussians.position))
+    feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_params.camera_position,
+                           grad_out=sh_out)
   else:
+    if grad_out is not None:
+      raise ValueError("grad_out with use_sh=False: gather the features yourself or use plain autograd")
     feats = gaussians.feature[indexes]
   return render_projected(indexes, g2d, feats, depth, camera_params, config,
                           render_median_depth=render_median_depth, **options)

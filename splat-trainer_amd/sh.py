@@ -24,7 +24,7 @@ def _stream():
 
 class _SHFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, sh_features, positions, indexes, camera_pos):
+  def forward(ctx, sh_features, positions, indexes, camera_pos, grad_out):
     lib = _lib.load()
     sh = sh_features.detach().to(torch.float32).contiguous()
     pos = positions.detach().to(torch.float32).contiguous()
@@ -35,6 +35,7 @@ class _SHFn(torch.autograd.Function):
     _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(out), _stream()),
                "gsr_sh_forward")
     ctx.save_for_backward(sh, pos, idx, cam)
+    ctx.grad_out = grad_out
     return out
 
   @staticmethod
@@ -42,23 +43,31 @@ class _SHFn(torch.autograd.Function):
     lib = _lib.load()
     sh, pos, idx, cam = ctx.saved_tensors
     N, _, K = sh.shape
-    d_sh = torch.zeros(N, 3, K, dtype=torch.float32, device=pos.device)
-    d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[1] else None
     M = idx.shape[0]
+    go = ctx.grad_out
+    if go is not None:                       # fused "+=" into caller-owned buffers (see renderer.GradOut)
+      d_sh, d_pos = go
+    else:
+      alloc = torch.empty if M == N else torch.zeros
+      d_sh = alloc(N, 3, K, dtype=torch.float32, device=pos.device)
+      d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[1] else None
     if M > 0:
       g = d_out.detach().to(torch.float32).contiguous()
       _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(d_sh),
-                                     _ptr(d_pos), _stream()), "gsr_sh_backward")
-    return d_sh, d_pos, None, None
+                                     _ptr(d_pos), 1 if go is not None else 0, _stream()), "gsr_sh_backward")
+    if go is not None:
+      return None, None, None, None, None
+    return d_sh, d_pos, None, None, None
 
 
 def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: torch.Tensor,
-                   camera_pos: torch.Tensor) -> torch.Tensor:
+                   camera_pos: torch.Tensor, grad_out=None) -> torch.Tensor:
   """``sh_features (N,3,K)``, ``positions (N,3)``, ``indexes (M,) int64``, ``camera_pos (3,)`` -> ``(M,3)``.
 
   colour_c = 0.5 + sum_k sh[idx, c, k] * Y_k(normalize(positions[idx] - camera_pos)), K in {1,4,9,16}
   (degrees 0..3, basis order k = n(n+1)+m as splat_trainer/scene/mlp/rsh.py).  Differentiable wrt
-  ``sh_features`` and, through the view direction, ``positions``; the caller clamps (transfer_sh.py:50)."""
+  ``sh_features`` and, through the view direction, ``positions``; the caller clamps (transfer_sh.py:50).
+  ``grad_out=(d_sh, d_positions)``: optional fused accumulation, see ``renderer.GradOut``."""
   for t in (sh_features, positions, indexes, camera_pos):
     if not t.is_cuda:
       raise _lib.GsplatHipError("evaluate_sh_at runs only on a HIP device; there is no CPU fallback")
@@ -66,4 +75,4 @@ def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: 
     raise ValueError(f"sh_features must be (N,3,K) with K in (1,4,9,16), got {tuple(sh_features.shape)}")
   if indexes.dtype != torch.int64:
     raise TypeError("indexes must be int64")
-  return _SHFn.apply(sh_features, positions, indexes, camera_pos)
+  return _SHFn.apply(sh_features, positions, indexes, camera_pos, grad_out)

@@ -197,3 +197,37 @@ def test_full_size_properties_config2(n, w, h):
     ty, tx = t // tiles_x, t % tiles_x
     ys, xs = slice(ty * 16, min(ty * 16 + 16, h)), slice(tx * 16, min(tx * 16 + 16, w))
     assert (img[ys, xs] - out.image[ys, xs]).abs().max().item() < 1e-4
+
+
+def test_grad_out_fused_accumulation_equals_autograd():
+  """renderer.GradOut: backward kernels add straight into caller buffers (the parameters' .grad over the
+  cameras of a batch, trainer.py:500-514).  Must equal plain autograd accumulation, bit for bit per camera sum,
+  including with an odd N (row alignment inside the flat collective buffer) and a culled subset."""
+  from splat_trainer_amd.distributed import GradBucket
+  g, cams = synthetic.scene_b(30_001, 320, 200, sh_degree=2, seed=9, radius=1.4)
+  dev = "cuda"
+  names = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
+
+  def leaves():
+    return [getattr(g, n).clone().to(dev).requires_grad_(True) for n in names]
+
+  def scene_of(ps):
+    return sta.Gaussians3D(position=ps[0], log_scaling=ps[1], rotation=ps[2], alpha_logit=ps[3], feature=ps[4])
+
+  # plain autograd, two cameras accumulate into .grad
+  pa = leaves()
+  for cam in cams[:2]:
+    r = sta.render_gaussians(scene_of(pa), cam.to(dev), CFG, use_sh=True)
+    ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+  assert 0 < r.points.idx.shape[0] < 30_001
+  # fused accumulation into a flat bucket
+  pb = leaves()
+  bucket = GradBucket(pb, world_size=1, extra=7)
+  go = sta.GradOut(**{n: v for n, v in zip(names, bucket.views)})
+  for cam in cams[:2]:
+    r = sta.render_gaussians(scene_of(pb), cam.to(dev), CFG, use_sh=True, grad_out=go)
+    ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+  for a, b, n in zip(pa, pb, names):
+    assert b.grad.data_ptr() == bucket.views[names.index(n)].data_ptr()
+    assert rel_err(b.grad, a.grad) < 1e-6, n
+    assert b.grad.data_ptr() % 16 == 0

@@ -84,76 +84,79 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
 
-  // pixel p = 2h + i : half h (rows py0 + 8h), side i (cols px0 + 8i); packed over i
+  // pixel p = 2h + i : half h (rows py0 + 8h), side i (cols px0 + 8i); packed over i.
+  // A pixel is live while T >= T_eps; pixels outside the image start at T = 0 and are never written.
   v2f T2[2], col2[2][3], med2[2];
   int lastc[4];
-  bool done[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    T2[h] = GSR_V2(1.f); med2[h] = GSR_V2(0.f);
+    const bool in_y = (py0 + 8 * h) < H;
+    T2[h] = (v2f){(in_y && px0 < W) ? 1.f : 0.f, (in_y && (px0 + 8) < W) ? 1.f : 0.f};
+    med2[h] = GSR_V2(0.f);
     col2[h][0] = col2[h][1] = col2[h][2] = GSR_V2(0.f);
   }
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    lastc[p] = 0;
-    done[p] = !((px0 + 8 * (p & 1)) < W && (py0 + 8 * (p >> 1)) < H);
-  }
+  for (int p = 0; p < 4; ++p) lastc[p] = 0;
+  // lane 16r+15 ends up with the visibility total of pair (i + {0,2,1,3}[r]) of each group of four
+  const uint32_t vis_slot = (uint32_t)(((lane >> 4) & 1) * 2 + (lane >> 5));
 
-  bool all_done = (start >= end);
-  for (uint32_t base = start; base < end && !all_done; base += 64) {
-    const uint32_t n = min(64u, end - base);
-    float my_vis = 0.f;
-    Splat nxt = load_splat<C>(rec, sorted_rank, base);
-    for (uint32_t j = 0; j < n; ++j) {
-      const Splat s = nxt;
-      if (j + 1 < n) nxt = load_splat<C>(rec, sorted_rank, base + j + 1);     // prefetch (scalar loads)
-      const float dxa = fx0 - s.u, dya = fy0 - s.v;
-      const v2f dx2 = {dxa, dxa + 8.f};
-      const float B2 = s.B + s.B;
-      const int idx = (int)(base - start + j) + 1;
-      v2f wsum2 = GSR_V2(0.f);
+  if (start < end) {
+    Splat nxt = load_splat<C>(rec, sorted_rank, start);
+    for (uint32_t i = start; i < end; i += 4) {
+      float wq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float dy = h ? dya + 8.f : dya;
-        const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
-        const bool in0 = !done[2 * h] && q.x <= rp.q_max;
-        const bool in1 = !done[2 * h + 1] && q.y <= rp.q_max;
-        if (__ballot(in0 || in1) != 0ull) {
-          const v2f G = eval_G2(q);
-          const v2f a_raw = G * s.op;
-          v2f alpha = __builtin_elementwise_min(a_raw, GSR_V2(rp.clamp_max_alpha));
-          const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
-          const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
-          alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
-          const v2f w = alpha * T2[h];
-          col2[h][0] = __builtin_elementwise_fma(w, GSR_V2(s.f0), col2[h][0]);
-          if (C > 1) col2[h][1] = __builtin_elementwise_fma(w, GSR_V2(s.f1), col2[h][1]);
-          if (C > 2) col2[h][2] = __builtin_elementwise_fma(w, GSR_V2(s.f2), col2[h][2]);
-          wsum2 += w;
-          T2[h] = T2[h] * (GSR_V2(1.f) - alpha);
-          if (hit0) lastc[2 * h] = idx;
-          if (hit1) lastc[2 * h + 1] = idx;
-          if (MEDIAN) {
-            if (hit0 && med2[h].x == 0.f && T2[h].x < 0.5f) med2[h].x = s.depth;
-            if (hit1 && med2[h].y == 0.f && T2[h].y < 0.5f) med2[h].y = s.depth;
+      for (int m = 0; m < 4; ++m) {
+        if (i + m < end) {                                               // wave-uniform
+          const Splat s = nxt;
+          if (i + m + 1 < end) nxt = load_splat<C>(rec, sorted_rank, i + m + 1);   // prefetch (scalar loads)
+          const float dxa = fx0 - s.u, dya = fy0 - s.v;
+          const v2f dx2 = {dxa, dxa + 8.f};
+          const float B2 = s.B + s.B;
+          const int idx = (int)(i - start) + m + 1;
+          v2f wsum2 = GSR_V2(0.f);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float dy = h ? dya + 8.f : dya;
+            const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+            const bool in0 = T2[h].x >= rp.T_eps && q.x <= rp.q_max;
+            const bool in1 = T2[h].y >= rp.T_eps && q.y <= rp.q_max;
+            if (__ballot(in0 || in1) != 0ull) {
+              const v2f G = eval_G2(q);
+              const v2f a_raw = G * s.op;
+              v2f alpha = __builtin_elementwise_min(a_raw, GSR_V2(rp.clamp_max_alpha));
+              const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
+              const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
+              alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
+              const v2f w = alpha * T2[h];
+              col2[h][0] = __builtin_elementwise_fma(w, GSR_V2(s.f0), col2[h][0]);
+              if (C > 1) col2[h][1] = __builtin_elementwise_fma(w, GSR_V2(s.f1), col2[h][1]);
+              if (C > 2) col2[h][2] = __builtin_elementwise_fma(w, GSR_V2(s.f2), col2[h][2]);
+              wsum2 += w;
+              T2[h] = T2[h] * (GSR_V2(1.f) - alpha);
+              if (hit0) lastc[2 * h] = idx;
+              if (hit1) lastc[2 * h + 1] = idx;
+              if (MEDIAN) {
+                if (hit0 && med2[h].x == 0.f && T2[h].x < 0.5f) med2[h].x = s.depth;
+                if (hit1 && med2[h].y == 0.f && T2[h].y < 0.5f) med2[h].y = s.depth;
+              }
+            }
           }
-          if (hit0 && T2[h].x < rp.T_eps) done[2 * h] = true;
-          if (hit1 && T2[h].y < rp.T_eps) done[2 * h + 1] = true;
+          wq[m] = wsum2.x + wsum2.y;
         }
       }
       if (VIS) {
-        const float wsum = wsum2.x + wsum2.y;
-        if (__ballot(wsum > 0.f) != 0ull) {
-          const float tot = gsr_wave_sum(wsum);
-          if ((uint32_t)lane == j) my_vis = tot;
+        // four pairs reduced at once, transposing: swap32 (4 -> 2 registers), swap16 (2 -> 1), then 4 row steps
+        float r = gsr_swap16_add(gsr_swap32_add(wq[0], wq[1]), gsr_swap32_add(wq[2], wq[3]));
+        r = gsr_row_sum_to_lane15(r);
+        const uint32_t pos = i + vis_slot;
+        if ((lane & 15) == 15 && pos < end) {
+          // sorted-position copy (read back coalesced by the backward pass) + per-instance copy (per-splat sums)
+          pair_vis[pos] = r;
+          if (r > 0.f) vis_partial[sorted_inst[pos]] = r;
         }
       }
-      if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) { all_done = true; break; }
-    }
-    if (VIS && (uint32_t)lane < n) {
-      // sorted-position copy (read back coalesced by the backward pass) + per-instance copy (per-splat reduction)
-      pair_vis[base + lane] = my_vis;
-      if (my_vis > 0.f) vis_partial[sorted_inst[base + lane]] = my_vis;
+      const bool live = T2[0].x >= rp.T_eps || T2[0].y >= rp.T_eps || T2[1].x >= rp.T_eps || T2[1].y >= rp.T_eps;
+      if (__ballot(live) == 0ull) break;
     }
   }
 

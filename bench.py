@@ -140,7 +140,7 @@ def main():
   position, log_scaling, rotation, alpha_logit, feature = params
   bucket = GradBucket(params, world, extra=N)              # + the per-point `visible` accumulator (mlp_scene.py:244)
   my_cams = [cams[j].to(dev) for j in shard_cameras(world, rank, world)]   # one camera per rank per step
-  target = 0.5
+  target_image = torch.full((w["h"], w["w"], 3), 0.5, device=dev)
   scene = sta.Gaussians3D(position=position, rotation=rotation, log_scaling=log_scaling, alpha_logit=alpha_logit,
                           feature=feature)
   # gradients accumulate straight into the flat collective buffer (the reference accumulates into .grad over
@@ -154,7 +154,7 @@ def main():
     for cam in my_cams:
       with torch.enable_grad():
         r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out)
-        loss = ((r.image.clamp(0, 1) - target) ** 2).mean()
+        loss = torch.nn.functional.mse_loss(r.image.clamp(0, 1), target_image)    # trainer.py:472-475
         loss.backward()
       bucket.extra.index_add_(0, r.points.idx, r.points.visibility)
       last["r"] = r

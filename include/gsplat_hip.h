@@ -55,7 +55,7 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 2) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 4) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -68,6 +68,10 @@ size_t gsr_sort_workspace_bytes(int64_t n);
 int gsr_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
                        int vals_are_iota, int begin_bit, int end_bit, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* Same, carrying a second value array with every key (the tile sort moves instance id + depth rank). */
+int gsr_sort_pairs2_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
+                        uint32_t* vals2_b, int64_t n, int vals_are_iota, int begin_bit, int end_bit, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- K1 frustum cull + compaction  (project_to_image, first half) --------------------------------------- */
 size_t gsr_cull_workspace_bytes(int64_t N);
@@ -92,14 +96,15 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
 
 /* ---- K3 spherical-harmonics colour forward / backward  (evaluate_sh_at) --------------------------------- */
 /* sh_features [N,3,K], K in {1,4,9,16}; colour = 0.5 + sum_k sh[c][k] Y_k(normalize(p - camera_pos)). */
+/* jacobian_out [M,9] or NULL: d colour / d position (row-major 3x3 per splat), saved for the backward pass. */
 int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
-                   const float* camera_pos, float* colors_out, void* stream);
+                   const float* camera_pos, float* colors_out, float* jacobian_out, void* stream);
 /* d_sh_features [N,3,K] and d_positions [N,3] (may be NULL): rows ``indexes`` are written (accumulate = 0, pass
  * zeros) or added to (accumulate = 1).
  * d_positions is the gradient through the view direction normalize(p - camera_pos). */
 int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const float* positions, const int64_t* indexes,
-                    int64_t M, int32_t K, const float* camera_pos, float* d_sh_features, float* d_positions,
-                    int32_t accumulate, void* stream);
+                    int64_t M, int32_t K, const float* camera_pos, const float* jacobian /* [M,9] or NULL */,
+                    float* d_sh_features, float* d_positions, int32_t accumulate, void* stream);
 
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */
 /* depth -> sortable u32 keys */
@@ -113,10 +118,9 @@ int gsr_tile_count(const float* gaussians2d, const float* depth, const float* fe
 /* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id, inst2rank[...] = k. */
 int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
                   const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, void* stream);
-/* From tile-sorted (keys, instance ids): per-tile [start, end) and the rank of every sorted instance.
- * tile_range must be zero-filled by the caller: [num_tiles, 2] uint32. */
-int gsr_tile_ranges(const uint32_t* sorted_keys, const uint32_t* sorted_inst, const uint32_t* inst2rank, int64_t O,
-                    int32_t num_tiles, uint32_t* tile_range, uint32_t* sorted_rank_out, void* stream);
+/* From the tile-sorted keys: per-tile [start, end).  tile_range must be zero-filled by the caller:
+ * [num_tiles, 2] uint32. */
+int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range, void* stream);
 
 /* ---- K6 alpha-composite forward ------------------------------------------------------------------------- */
 /* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;

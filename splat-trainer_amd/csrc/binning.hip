@@ -86,16 +86,13 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict_
       }
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys,
-                                                          const uint32_t* __restrict__ inst,
-                                                          const uint32_t* __restrict__ inst2rank, int64_t O,
-                                                          uint32_t* __restrict__ range, uint32_t* __restrict__ rank_out) {
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int64_t O,
+                                                          uint32_t* __restrict__ range) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= O) return;
   const uint32_t t = keys[i];
   if (i == 0 || keys[i - 1] != t) range[2 * t] = (uint32_t)i;
   if (i == O - 1 || keys[i + 1] != t) range[2 * t + 1] = (uint32_t)(i + 1);
-  rank_out[i] = inst2rank[inst[i]];
 }
 
 // Instances of rank k occupy the contiguous pre-sort ids [offsets[k], offsets[k] + count[k]); summing them in id
@@ -113,6 +110,9 @@ __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict
   vis[order[k]] = acc;
 }
 
+// One block = 256 consecutive depth ranks = one CONTIGUOUS range of instance slots.  The range is streamed through
+// LDS in 256-slot chunks with fully coalesced 16-byte loads; each thread then adds the slots of its own rank from
+// LDS in ascending id order (fixed association order -> bit-reproducible).
 template <int C>
 __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restrict__ partial,
                                                           const float* __restrict__ vis_partial,
@@ -121,19 +121,46 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
                                                           const uint32_t* __restrict__ order, int64_t M,
                                                           float* __restrict__ dg2d, float* __restrict__ dfeat,
                                                           float* __restrict__ prune, float* __restrict__ split) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= M) return;
-  const uint32_t b = offsets[k], n = count[k];
+  constexpr int CH = 256;
+  __shared__ float4 s_part[CH * 3];
+  __shared__ float s_vis[CH];
+  __shared__ uint32_t s_lo, s_hi;
+  const int64_t k0 = (int64_t)blockIdx.x * 256;
+  const int64_t k = k0 + threadIdx.x;
+  const bool have = k < M;
+  const uint32_t b = have ? offsets[k] : 0u, n = have ? count[k] : 0u;
+  if (threadIdx.x == 0) s_lo = b;
+  const int64_t klast = (k0 + 255 < M ? k0 + 255 : M - 1);
+  if (k == klast) s_hi = b + n;
+  __syncthreads();
+  const uint32_t lo = s_lo, hi = s_hi;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-  for (uint32_t j = 0; j < n; ++j) {
-    if (vis_partial[b + j] > 0.f) {          // untouched (tile,splat) pairs were never written
-      const float4* p = reinterpret_cast<const float4*>(partial + (size_t)GSR_PARTIAL_FLOATS * (b + j));
-      const float4 p0 = p[0], p1 = p[1], p2 = p[2];
-      a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
-      a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
-      a2.x += p2.x; a2.y += p2.y; a2.z += p2.z;
+  const float4* src = reinterpret_cast<const float4*>(partial);
+  for (uint32_t c = lo; c < hi; c += CH) {
+    const uint32_t m = min((uint32_t)CH, hi - c);
+    const bool mine = threadIdx.x < m;
+    const float v = mine ? vis_partial[c + threadIdx.x] : 0.f;
+    s_vis[threadIdx.x] = v;
+    // slots never written by the backward pass (vis == 0) hold garbage: copied but never summed
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const uint32_t f = threadIdx.x + t * CH;                 // float4 index inside the chunk
+      if (f < 3 * m) s_part[f] = src[(size_t)3 * c + f];
     }
+    __syncthreads();
+    const uint32_t j0 = max(b, c), j1 = min(b + n, c + m);
+    for (uint32_t j = j0; j < j1; ++j) {
+      const uint32_t l = j - c;
+      if (s_vis[l] > 0.f) {
+        const float4 p0 = s_part[3 * l], p1 = s_part[3 * l + 1], p2 = s_part[3 * l + 2];
+        a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+        a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+        a2.x += p2.x; a2.y += p2.y; a2.z += p2.z;
+      }
+    }
+    __syncthreads();
   }
+  if (!have) return;
   const int64_t s = order[k];
   float* g = dg2d + 6 * s;
   *reinterpret_cast<float2*>(g) = make_float2(a0.x, a0.y);
@@ -192,14 +219,12 @@ int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t 
   return GSR_OK;
 }
 
-int gsr_tile_ranges(const uint32_t* sorted_keys, const uint32_t* sorted_inst, const uint32_t* inst2rank, int64_t O,
-                    int32_t num_tiles, uint32_t* tile_range, uint32_t* sorted_rank_out, void* stream_) {
+int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (O < 0 || num_tiles <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (O == 0) return GSR_OK;
-  if (!sorted_keys || !sorted_inst || !inst2rank || !tile_range || !sorted_rank_out) return GSR_ERR_INVALID_ARGUMENT;
-  tile_ranges_kernel<<<grid_for(O, 256), 256, 0, stream>>>(sorted_keys, sorted_inst, inst2rank, O, tile_range,
-                                                          sorted_rank_out);
+  if (!sorted_keys || !tile_range) return GSR_ERR_INVALID_ARGUMENT;
+  tile_ranges_kernel<<<grid_for(O, 256), 256, 0, stream>>>(sorted_keys, O, tile_range);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restric
 template <int K>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ sh, const float* __restrict__ pos,
                                                      const int64_t* __restrict__ idx, int64_t M,
-                                                     const float* __restrict__ cam_pos, float* __restrict__ out) {
+                                                     const float* __restrict__ cam_pos, float* __restrict__ out,
+                                                     float* __restrict__ jac) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const int64_t i = idx[m];
@@ -142,13 +143,40 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
     c[ch] = acc;
   }
   out[3 * m] = c[0]; out[3 * m + 1] = c[1]; out[3 * m + 2] = c[2];
+  if (jac != nullptr) {
+    // d colour_c / d position (3x3), through the view direction d = v/|v|: saved so that the backward pass
+    // does not have to stream the 12K-byte coefficient row again
+    float J[9];
+    if (K > 1) {
+      float dYx[K], dYy[K], dYz[K];
+      const float x = dx * inv, y = dy * inv, z = dz * inv;
+      gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+          const float w = row[ch * K + k];
+          gx += w * dYx[k]; gy += w * dYy[k]; gz += w * dYz[k];
+        }
+        const float dot = gx * x + gy * y + gz * z;
+        J[3 * ch] = (gx - x * dot) * inv; J[3 * ch + 1] = (gy - y * dot) * inv; J[3 * ch + 2] = (gz - z * dot) * inv;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) J[t] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) jac[9 * m + t] = J[t];
+  }
 }
 
 template <int K, bool ACC>
 __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ dcol, const float* __restrict__ sh,
                                                      const float* __restrict__ pos, const int64_t* __restrict__ idx,
                                                      int64_t M, const float* __restrict__ cam_pos,
-                                                     float* __restrict__ dsh, float* __restrict__ dpos) {
+                                                     float* __restrict__ dsh, float* __restrict__ dpos,
+                                                     const float* __restrict__ jac) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const int64_t i = idx[m];
@@ -177,7 +205,15 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ d
       for (int k = 0; k < K; ++k) row[ch * K + k] = ACC ? row[ch * K + k] + g * Y[k] : g * Y[k];
     }
   }
-  if (dpos != nullptr && K > 1) {
+  if (dpos != nullptr && jac != nullptr) {
+    const float* J = jac + 9 * m;
+    const float px_ = g3[0] * J[0] + g3[1] * J[3] + g3[2] * J[6];
+    const float py_ = g3[0] * J[1] + g3[1] * J[4] + g3[2] * J[7];
+    const float pz_ = g3[0] * J[2] + g3[1] * J[5] + g3[2] * J[8];
+    dpos[3 * i] = ACC ? dpos[3 * i] + px_ : px_;
+    dpos[3 * i + 1] = ACC ? dpos[3 * i + 1] + py_ : py_;
+    dpos[3 * i + 2] = ACC ? dpos[3 * i + 2] + pz_ : pz_;
+  } else if (dpos != nullptr && K > 1) {
     // colour depends on the point through the view direction d = v/|v|:  dL/dp = (I - d d^T)/|v| * dL/dd
     float dYx[K], dYy[K], dYz[K];
     gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
@@ -211,7 +247,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 2; }
+int gsr_abi_version(void) { return 4; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -298,7 +334,7 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
 }
 
 int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
-                   const float* camera_pos, float* colors_out, void* stream_) {
+                   const float* camera_pos, float* colors_out, float* jacobian_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
@@ -306,18 +342,18 @@ int gsr_sh_forward(const float* sh_features, const float* positions, const int64
   if (!sh_features || !positions || !indexes || !camera_pos || !colors_out) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
   switch (K) {
-    case 1: sh_fwd_kernel<1><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
-    case 4: sh_fwd_kernel<4><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
-    case 9: sh_fwd_kernel<9><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
-    default: sh_fwd_kernel<16><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out); break;
+    case 1: sh_fwd_kernel<1><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
+    case 4: sh_fwd_kernel<4><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
+    case 9: sh_fwd_kernel<9><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
+    default: sh_fwd_kernel<16><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
   }
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
 
 int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const float* positions, const int64_t* indexes,
-                    int64_t M, int32_t K, const float* camera_pos, float* d_sh_features, float* d_positions,
-                    int32_t accumulate, void* stream_) {
+                    int64_t M, int32_t K, const float* camera_pos, const float* jacobian, float* d_sh_features,
+                    float* d_positions, int32_t accumulate, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
@@ -327,20 +363,20 @@ int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const flo
   const unsigned g = grid_for(M, 256);
   switch (K) {
     case 1:
-      if (accumulate) sh_bwd_kernel<1, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
-      else sh_bwd_kernel<1, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      if (accumulate) sh_bwd_kernel<1, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
+      else sh_bwd_kernel<1, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
       break;
     case 4:
-      if (accumulate) sh_bwd_kernel<4, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
-      else sh_bwd_kernel<4, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      if (accumulate) sh_bwd_kernel<4, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
+      else sh_bwd_kernel<4, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
       break;
     case 9:
-      if (accumulate) sh_bwd_kernel<9, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
-      else sh_bwd_kernel<9, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      if (accumulate) sh_bwd_kernel<9, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
+      else sh_bwd_kernel<9, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
       break;
     default:
-      if (accumulate) sh_bwd_kernel<16, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
-      else sh_bwd_kernel<16, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions);
+      if (accumulate) sh_bwd_kernel<16, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
+      else sh_bwd_kernel<16, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
       break;
   }
   GSR_CHECK_LAUNCH();

@@ -145,21 +145,25 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
 }
 
 // ------------------------------------------------------------------------------------------ radix sort
+// Stable LSD radix sort, 8-bit digits, four launches per pass:
+//   rs_hist        per-block digit histogram (LDS atomics) -> hist[digit][block];  rs_row_total: totals per digit
+//   rs_digit_scan  one block per digit: base = sum of the totals of smaller digits, then an exclusive scan of the
+//                  digit's row over blocks
+//   rs_scatter     per-round (256 elements) ballot-match ranking inside each wave, wave counts through LDS;
+//                  elements keep their input order inside every digit bucket (stable).  Up to two value arrays.
 constexpr int RS_THREADS = 256;
-constexpr int RS_ROUNDS = 16;
-constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;   // 4096 pairs per block
 constexpr int RS_BINS = 256;
 
-// per-block digit histogram, stored digit-major: hist[digit * num_blocks + block]
+inline int rs_rounds_for(int64_t n) { return n < (4ll << 20) ? 4 : 16; }     // 1024 or 4096 pairs per block
+
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
-                                                             uint32_t mask, uint32_t* __restrict__ hist,
+                                                             uint32_t mask, int rounds, uint32_t* __restrict__ hist,
                                                              uint32_t num_blocks) {
   __shared__ uint32_t s_hist[RS_BINS];
   s_hist[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * RS_TILE;
-#pragma unroll 4
-  for (int r = 0; r < RS_ROUNDS; ++r) {
+  const uint32_t base = blockIdx.x * (uint32_t)(rounds * RS_THREADS);
+  for (int r = 0; r < rounds; ++r) {
     uint32_t idx = base + r * RS_THREADS + threadIdx.x;
     if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & mask], 1u);
   }
@@ -167,19 +171,69 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
   hist[threadIdx.x * num_blocks + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// stable scatter: elements keep their input order inside every digit bucket.
+// one block per digit: total count of the digit over all blocks (global atomics on 256 hot words measured 3x slower)
+__global__ __launch_bounds__(RS_THREADS) void rs_row_total_kernel(const uint32_t* __restrict__ hist, uint32_t num_blocks,
+                                                                  uint32_t* __restrict__ digit_total) {
+  __shared__ uint32_t s_wave[4];
+  const uint32_t* row = hist + (size_t)blockIdx.x * num_blocks;
+  uint32_t t = 0;
+  for (uint32_t b = threadIdx.x; b < num_blocks; b += RS_THREADS) t += row[b];
+  t = gsr_wave_sum_u32(t);
+  if (gsr_lane() == 0) s_wave[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) digit_total[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(uint32_t* __restrict__ hist, uint32_t num_blocks,
+                                                                   const uint32_t* __restrict__ digit_total) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_carry;
+  const uint32_t d = blockIdx.x;
+  const int lane = gsr_lane(), wave = threadIdx.x >> 6;
+  // base of this digit = total count of all smaller digits
+  uint32_t t = (threadIdx.x < d) ? digit_total[threadIdx.x] : 0u;
+  t = gsr_wave_sum_u32(t);
+  if (lane == 0) s_wave[wave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) s_carry = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  __syncthreads();
+  uint32_t* row = hist + (size_t)d * num_blocks;
+  for (uint32_t b0 = 0; b0 < num_blocks; b0 += RS_THREADS) {
+    const uint32_t b = b0 + threadIdx.x;
+    const uint32_t v = (b < num_blocks) ? row[b] : 0u;
+    const uint32_t incl = gsr_wave_scan_incl_u32(v);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = s_wave[w];
+      if (w < wave) wbase += c;
+      total += c;
+    }
+    if (b < num_blocks) row[b] = s_carry + wbase + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += total;
+    __syncthreads();
+  }
+}
+
+template <bool TWO>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,   // null -> iota
+                                                                const uint32_t* __restrict__ vals2_in,
                                                                 uint32_t* __restrict__ keys_out,
-                                                                uint32_t* __restrict__ vals_out, uint32_t n, int shift,
-                                                                uint32_t mask, const uint32_t* __restrict__ offsets,
+                                                                uint32_t* __restrict__ vals_out,
+                                                                uint32_t* __restrict__ vals2_out, uint32_t n, int shift,
+                                                                uint32_t mask, int rounds,
+                                                                const uint32_t* __restrict__ offsets,
                                                                 uint32_t num_blocks) {
   __shared__ uint32_t s_base[RS_BINS];        // next output slot of each digit for this block
   __shared__ uint32_t s_wcnt[4][RS_BINS];     // per-wave digit counts of the current round
-  const int lane = gsr_lane(), wave = threadIdx.x >> 6;
+  const int wave = threadIdx.x >> 6;
   s_base[threadIdx.x] = offsets[threadIdx.x * num_blocks + blockIdx.x];
-  const uint32_t base = blockIdx.x * RS_TILE;
-  for (int r = 0; r < RS_ROUNDS; ++r) {
+  const uint32_t base = blockIdx.x * (uint32_t)(rounds * RS_THREADS);
+  for (int r = 0; r < rounds; ++r) {
     const uint32_t round_base = base + r * RS_THREADS;
     if (round_base >= n) break;                               // uniform over the block
 #pragma unroll
@@ -187,10 +241,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     __syncthreads();
     const uint32_t idx = round_base + threadIdx.x;
     const bool valid = idx < n;
-    uint32_t key = 0, val = 0, digit = 0;
+    uint32_t key = 0, val = 0, val2 = 0, digit = 0;
     if (valid) {
       key = keys_in[idx];
       val = vals_in ? vals_in[idx] : idx;
+      if (TWO) val2 = vals2_in[idx];
       digit = (key >> shift) & mask;
     }
     // lanes of this wave holding the same digit
@@ -210,11 +265,67 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
         if (w < wave) off += s_wcnt[w][digit];
       keys_out[off] = key;
       vals_out[off] = val;
+      if (TWO) vals2_out[off] = val2;
     }
     __syncthreads();
     s_base[threadIdx.x] += s_wcnt[0][threadIdx.x] + s_wcnt[1][threadIdx.x] + s_wcnt[2][threadIdx.x] + s_wcnt[3][threadIdx.x];
     __syncthreads();
   }
+}
+
+size_t sort_ws_bytes(int64_t n) {
+  if (n <= 0) return 1024 * 5 + 256;
+  const uint64_t tile = (uint64_t)rs_rounds_for(n) * RS_THREADS;
+  const uint64_t nb = ((uint64_t)n + tile - 1) / tile;
+  const size_t hist = ((nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
+  return hist + 5 * RS_BINS * sizeof(uint32_t) + 256;        // + digit totals of up to 5 passes
+}
+
+int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
+              uint32_t* vals2_b, int64_t n, int vals_are_iota, int begin_bit, int end_bit, void* workspace,
+              size_t workspace_bytes, hipStream_t stream) {
+  const bool two = vals2_a != nullptr;
+  if (n < 0 || n > 0x7FFFFFFFll || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return GSR_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!keys_a || !vals_a || !keys_b || !vals_b || (two && !vals2_b))) return GSR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < sort_ws_bytes(n) || !workspace) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  if (n == 0) return 0;
+  const int rounds = rs_rounds_for(n);
+  const uint32_t tile = (uint32_t)(rounds * RS_THREADS);
+  const uint32_t nb = (uint32_t)((n + tile - 1) / tile);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
+  const size_t hist_bytes = (((size_t)nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
+  uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + hist_bytes);
+  int passes = (end_bit - begin_bit + 7) / 8;
+  if (passes < 1) passes = 1;
+  if (passes > 5) return GSR_ERR_INVALID_ARGUMENT;
+
+  uint32_t* kin = keys_a; uint32_t* kout = keys_b;
+  const uint32_t* vin = vals_are_iota ? nullptr : vals_a; uint32_t* vout = vals_b;
+  const uint32_t* v2in = vals2_a; uint32_t* v2out = vals2_b;
+  int where = 0;
+  for (int p = 0; p < passes; ++p) {
+    const int bit = begin_bit + 8 * p;
+    int bits = end_bit - bit; if (bits > 8) bits = 8; if (bits < 0) bits = 0;
+    const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
+    uint32_t* tot = totals + (size_t)p * RS_BINS;
+    rs_hist_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, rounds, hist, nb);
+    GSR_CHECK_LAUNCH();
+    rs_row_total_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
+    GSR_CHECK_LAUNCH();
+    rs_digit_scan_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
+    GSR_CHECK_LAUNCH();
+    if (two)
+      rs_scatter_kernel<true><<<nb, RS_THREADS, 0, stream>>>(kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask,
+                                                            rounds, hist, nb);
+    else
+      rs_scatter_kernel<false><<<nb, RS_THREADS, 0, stream>>>(kin, vin, nullptr, kout, vout, nullptr, (uint32_t)n, bit,
+                                                             mask, rounds, hist, nb);
+    GSR_CHECK_LAUNCH();
+    where ^= 1;
+    if (where == 1) { kin = keys_b; vin = vals_b; v2in = vals2_b; kout = keys_a; vout = vals_a; v2out = vals2_a; }
+    else            { kin = keys_a; vin = vals_a; v2in = vals2_a; kout = keys_b; vout = vals_b; v2out = vals2_b; }
+  }
+  return where;
 }
 
 }  // namespace
@@ -232,48 +343,25 @@ int gsr_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
   return scan_impl(in, out, (uint64_t)n, total_dev, reinterpret_cast<uint8_t*>(workspace), stream);
 }
 
-size_t gsr_sort_workspace_bytes(int64_t n) {
-  if (n <= 0) return 256;
-  uint64_t nb = ((uint64_t)n + RS_TILE - 1) / RS_TILE;
-  size_t hist = ((nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
-  return hist + scan_ws_bytes(nb * RS_BINS);
-}
+size_t gsr_sort_workspace_bytes(int64_t n) { return sort_ws_bytes(n); }
 
-// Sorts by key bits [begin_bit, end_bit).  Ping-pongs between (keys_a, vals_a) and (keys_b, vals_b); input is in
-// the *_a buffers (vals_are_iota != 0: the input values are 0..n-1 and vals_a is only scratch).  Returns (>= 0) 0 when the result is in the *_a
-// buffers and 1 when it is in the *_b buffers, or a negative error code.
+// Sorts by key bits [begin_bit, end_bit).  Ping-pongs between the *_a and *_b buffers; input is in the *_a buffers
+// (vals_are_iota != 0: the input values are 0..n-1 and vals_a is only scratch).  Returns (>= 0) 0 when the result
+// is in the *_a buffers and 1 when it is in the *_b buffers, or a negative error code.
 int gsr_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
                        int vals_are_iota, int begin_bit, int end_bit, void* workspace, size_t workspace_bytes,
                        void* stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (n < 0 || n > 0x7FFFFFFFll || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return GSR_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!keys_a || !vals_a || !keys_b || !vals_b)) return GSR_ERR_INVALID_ARGUMENT;
-  if (workspace_bytes < gsr_sort_workspace_bytes(n) || !workspace) return GSR_ERR_WORKSPACE_TOO_SMALL;
-  if (n == 0) return 0;
-  const uint32_t nb = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
-  size_t hist_bytes = (((size_t)nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
-  uint8_t* scan_ws = reinterpret_cast<uint8_t*>(workspace) + hist_bytes;
+  return sort_impl(keys_a, vals_a, nullptr, keys_b, vals_b, nullptr, n, vals_are_iota, begin_bit, end_bit, workspace,
+                   workspace_bytes, reinterpret_cast<hipStream_t>(stream_));
+}
 
-  uint32_t* kin = keys_a; uint32_t* kout = keys_b;
-  const uint32_t* vin = vals_are_iota ? nullptr : vals_a; uint32_t* vout = vals_b;
-  int where = 0;
-  bool first = true;
-  for (int bit = begin_bit; bit < end_bit || first; bit += 8) {
-    int bits = end_bit - bit; if (bits > 8) bits = 8; if (bits < 0) bits = 0;
-    uint32_t mask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
-    rs_hist_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, hist, nb);
-    GSR_CHECK_LAUNCH();
-    int rc = scan_impl(hist, hist, (uint64_t)nb * RS_BINS, nullptr, scan_ws, stream);
-    if (rc != GSR_OK) return rc;
-    rs_scatter_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, vin, kout, vout, (uint32_t)n, bit, mask, hist, nb);
-    GSR_CHECK_LAUNCH();
-    where ^= 1;
-    if (where == 1) { kin = keys_b; vin = vals_b; kout = keys_a; vout = vals_a; }
-    else            { kin = keys_a; vin = vals_a; kout = keys_b; vout = vals_b; }
-    first = false;
-  }
-  return where;
+// Same, carrying a second value array (vals2) along with every key.
+int gsr_sort_pairs2_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
+                        uint32_t* vals2_b, int64_t n, int vals_are_iota, int begin_bit, int end_bit, void* workspace,
+                        size_t workspace_bytes, void* stream_) {
+  if (n > 0 && !vals2_a) return GSR_ERR_INVALID_ARGUMENT;
+  return sort_impl(keys_a, vals_a, vals2_a, keys_b, vals_b, vals2_b, n, vals_are_iota, begin_bit, end_bit, workspace,
+                   workspace_bytes, reinterpret_cast<hipStream_t>(stream_));
 }
 
 }  // extern "C"

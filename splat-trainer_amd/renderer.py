@@ -253,20 +253,19 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
 
   # emit (tile id, instance) in depth order, stable-sort by tile id, find per-tile ranges
   tkeys_a, tkeys_b, tvals_a, tvals_b = _u32(O, dev), _u32(O, dev), _u32(O, dev), _u32(O, dev)
-  inst2rank = _u32(O, dev)
+  trank_a, trank_b = _u32(O, dev), _u32(O, dev)
   _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
-                               _ptr(inst2rank), stream), "gsr_tile_emit")
+                               _ptr(trank_a), stream), "gsr_tile_emit")
   tile_bits = max(1, int(math.ceil(math.log2(num_tiles)))) if num_tiles > 1 else 1
   tsort_bytes = lib.gsr_sort_workspace_bytes(O)
   tsort_ws = torch.empty(tsort_bytes, dtype=torch.uint8, device=dev)
-  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(tkeys_a), _ptr(tvals_a), _ptr(tkeys_b), _ptr(tvals_b), O, 1, 0,
-                                            tile_bits, _ptr(tsort_ws), tsort_bytes, stream),
-                     "gsr_sort_pairs_u32(tile)")
-  sorted_keys, st.sorted_inst = (tkeys_b, tvals_b) if where == 1 else (tkeys_a, tvals_a)
+  # values: instance id (implicit 0..O-1) and depth rank travel with the tile key
+  where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(tkeys_a), _ptr(tvals_a), _ptr(trank_a), _ptr(tkeys_b), _ptr(tvals_b),
+                                             _ptr(trank_b), O, 1, 0, tile_bits, _ptr(tsort_ws), tsort_bytes, stream),
+                     "gsr_sort_pairs2_u32(tile)")
+  sorted_keys, st.sorted_inst, st.sorted_rank = (tkeys_b, tvals_b, trank_b) if where == 1 else (tkeys_a, tvals_a, trank_a)
   st.tile_range = torch.zeros(num_tiles, 2, dtype=torch.int32, device=dev)
-  st.sorted_rank = _u32(O, dev)
-  _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), _ptr(st.sorted_inst), _ptr(inst2rank), O, num_tiles,
-                                 _ptr(st.tile_range), _ptr(st.sorted_rank), stream), "gsr_tile_ranges")
+  _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), O, num_tiles, _ptr(st.tile_range), stream), "gsr_tile_ranges")
 
   st.vis_partial = torch.zeros(O, dtype=torch.float32, device=dev) if need_vis_partial else None
   st.pair_vis = torch.empty(O, dtype=torch.float32, device=dev) if need_vis_partial else None

@@ -24,7 +24,7 @@ def _stream():
 
 class _SHFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, sh_features, positions, indexes, camera_pos, grad_out):
+  def forward(ctx, sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad):
     lib = _lib.load()
     sh = sh_features.detach().to(torch.float32).contiguous()
     pos = positions.detach().to(torch.float32).contiguous()
@@ -32,9 +32,13 @@ class _SHFn(torch.autograd.Function):
     idx = indexes.contiguous()
     M, K = idx.shape[0], sh.shape[2]
     out = torch.empty(M, 3, dtype=torch.float32, device=sh.device)
-    _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(out), _stream()),
+    # d colour / d position is cheap to form while the coefficient row is in registers; saving it (36 B per
+    # splat) spares the backward pass a second sweep over the 12K-byte rows
+    jac = torch.empty(M, 9, dtype=torch.float32, device=sh.device) if (want_pos_grad and K > 1 and M > 0) else None
+    _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(out), _ptr(jac), _stream()),
                "gsr_sh_forward")
     ctx.save_for_backward(sh, pos, idx, cam)
+    ctx.jac = jac
     ctx.grad_out = grad_out
     return out
 
@@ -53,11 +57,12 @@ class _SHFn(torch.autograd.Function):
       d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[1] else None
     if M > 0:
       g = d_out.detach().to(torch.float32).contiguous()
-      _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(d_sh),
-                                     _ptr(d_pos), 1 if go is not None else 0, _stream()), "gsr_sh_backward")
+      _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(ctx.jac),
+                                     _ptr(d_sh), _ptr(d_pos), 1 if go is not None else 0, _stream()),
+                 "gsr_sh_backward")
     if go is not None:
-      return None, None, None, None, None
-    return d_sh, d_pos, None, None, None
+      return None, None, None, None, None, None
+    return d_sh, d_pos, None, None, None, None
 
 
 def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: torch.Tensor,
@@ -75,4 +80,5 @@ def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: 
     raise ValueError(f"sh_features must be (N,3,K) with K in (1,4,9,16), got {tuple(sh_features.shape)}")
   if indexes.dtype != torch.int64:
     raise TypeError("indexes must be int64")
-  return _SHFn.apply(sh_features, positions, indexes, camera_pos, grad_out)
+  want_pos_grad = torch.is_grad_enabled() and (positions.requires_grad or (grad_out is not None and grad_out[1] is not None))
+  return _SHFn.apply(sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad)

@@ -78,3 +78,24 @@ def test_sort_rejects_bad_arguments():
   t = torch.zeros(16, dtype=torch.int32, device="cuda")
   assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 40, _ptr(t), 64, _stream()) == -1
   assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 32, _ptr(t), 8, _stream()) == -2
+
+
+@pytest.mark.parametrize("n,bits", [(1, 13), (1023, 13), (200_003, 13), (5_000_011, 15)])
+def test_radix_sort_two_values(n, bits):
+  """The tile sort carries (instance id = iota, depth rank) with every tile key."""
+  lib = _lib.load()
+  rng = np.random.default_rng(n)
+  keys = rng.integers(0, 2 ** bits, size=n, dtype=np.uint64).astype(np.uint32)
+  vals2 = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+  ka = torch.from_numpy(keys.view(np.int32)).cuda()
+  v2a = torch.from_numpy(vals2.view(np.int32)).cuda()
+  va, kb, vb, v2b = (torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(4))
+  nbytes = lib.gsr_sort_workspace_bytes(n)
+  ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+  where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(ka), _ptr(va), _ptr(v2a), _ptr(kb), _ptr(vb), _ptr(v2b), n, 1, 0, bits,
+                                             _ptr(ws), nbytes, _stream()), "sort2")
+  k, v, v2 = (kb, vb, v2b) if where == 1 else (ka, va, v2a)
+  order = np.argsort(keys, kind="stable")
+  assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
+  assert np.array_equal(v.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+  assert np.array_equal(v2.cpu().numpy().view(np.uint32), vals2[order])

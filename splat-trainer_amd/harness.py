@@ -1,0 +1,151 @@
+"""Minimal harness around the rasterizer path for BASELINE config c4: a short training loop with the
+reference's densify/prune arithmetic, so that the dynamic-splat-count use of the boundary is exercised
+end to end.  It restates, for the harness only, the consumers the reference keeps untouched:
+
+  evaluate_backward_with ........ splat_trainer/trainer/trainer.py:500-514  (per-camera render + loss + backward,
+                                   gradients accumulate across the cameras of a batch)
+  PointState / TargetController .. splat_trainer/controller/point_state.py:34-110,
+                                   splat_trainer/controller/target_controller.py:73-126   (controller_math.py)
+  split_gaussians_uniform ........ splat_trainer/gaussians/split.py:87-113  (k = 2, +/-0.7 sigma along a sampled
+                                   axis, that axis scaled by 1/sqrt(2))
+  scene.split_and_prune .......... splat_trainer/scene/mlp_scene.py:301-310 (keep_mask rows + appended splits)
+  scene.step (subset) ............ mlp_scene.py:236-237 (renormalise quaternions, clamp log_scaling to [-8, 8])
+
+The optimizer is plain torch Adam (the reference's sparse visibility-aware LaProp lives in taichi_splatting
+and is SURVEY.md section 8f "next").  Nothing here is on the measured hot path.
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .controller_math import PointState, find_split_prune_indexes
+from .data_types import CameraParams, Gaussians3D, RasterConfig
+from .renderer import render_gaussians
+
+PARAM_NAMES = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
+
+
+def quat_to_rotmat_xyzw(q: torch.Tensor) -> torch.Tensor:
+  q = F.normalize(q, dim=1)
+  x, y, z, w = q.unbind(-1)
+  return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+
+
+def point_basis(log_scaling: torch.Tensor, rotation: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
+  """split.py:16-20: R(q) * clamp_min(exp(log_s), eps) (columns scaled)."""
+  return quat_to_rotmat_xyzw(rotation) * torch.clamp_min(torch.exp(log_scaling), eps).unsqueeze(-2)
+
+
+def split_gaussians_uniform(points: dict, k: int = 2, sep: float = 0.7, random_axis: bool = True,
+                            eps: float = 1e-4, generator: Optional[torch.Generator] = None) -> dict:
+  """split.py:87-113 over a dict of row tensors."""
+  ls = points["log_scaling"]
+  if random_axis:
+    probs = F.normalize(torch.clamp_min(ls.exp(), eps), dim=1)
+    axis = torch.multinomial(probs, num_samples=1, generator=generator).squeeze(1)
+  else:
+    axis = torch.argmax(ls, dim=1)
+  axis = F.one_hot(axis, num_classes=3).to(ls.dtype)
+  values = torch.linspace(-sep, sep, k, device=ls.device)
+  samples = values.view(1, -1, 1) * axis.view(-1, 1, 3)                  # (n, k, 3) local offsets
+  scaling = 1.0 / math.sqrt(k)
+  basis = point_basis(ls, points["rotation"])                           # unscaled parent basis
+  offsets = (basis.repeat_interleave(k, dim=0) @ samples.reshape(-1, 3, 1)).reshape(-1, 3)
+  out = {name: t.repeat_interleave(k, dim=0) for name, t in points.items()}
+  out["log_scaling"] = (ls + math.log(scaling) * axis).repeat_interleave(k, dim=0)
+  out["position"] = out["position"] + offsets
+  return out
+
+
+@dataclass
+class TrainLog:
+  losses: List[float] = field(default_factory=list)
+  num_points: List[int] = field(default_factory=list)
+  mask_digests: List[str] = field(default_factory=list)
+
+
+class MiniTrainer:
+  """Replicated-parameter training loop: batch of cameras -> grads -> Adam -> (every ``densify_every`` its)
+  TargetController-style split/prune with buffer re-sizing."""
+
+  def __init__(self, gaussians: Gaussians3D, cameras: Sequence[CameraParams], targets: Sequence[torch.Tensor],
+               config: Optional[RasterConfig] = None, lr: float = 1e-3, densify_every: int = 25,
+               target_points: Optional[int] = None, prune_rate: float = 0.025, min_views: int = 5,
+               max_scale_px: float = 200.0, total_steps: int = 100, seed: int = 0):
+    self.config = config or RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+    self.cameras, self.targets = list(cameras), list(targets)
+    self.params = {n: getattr(gaussians, n).detach().clone().requires_grad_(True) for n in PARAM_NAMES}
+    self.lr, self.densify_every, self.total_steps = lr, densify_every, total_steps
+    self.target_points = target_points or int(1.1 * gaussians.position.shape[0])
+    self.prune_rate, self.min_views, self.max_scale_px = prune_rate, min_views, max_scale_px
+    self.device = gaussians.position.device
+    self.gen = torch.Generator(device=self.device).manual_seed(seed)
+    self.state = PointState.new_zeros(self.num_points, self.device)
+    self.step_idx = 0
+    self.log = TrainLog()
+    self._new_optimizer()
+
+  @property
+  def num_points(self) -> int:
+    return self.params["position"].shape[0]
+
+  def _new_optimizer(self):
+    self.opt = torch.optim.Adam([dict(params=[self.params[n]], lr=self.lr * (0.1 if n == "feature" else 1.0))
+                                 for n in PARAM_NAMES])
+
+  def scene(self) -> Gaussians3D:
+    return Gaussians3D(**self.params)
+
+  def training_step(self) -> float:
+    """trainer.py:531-545: evaluate_backward_with over the batch, then the optimizer step."""
+    self.opt.zero_grad(set_to_none=True)
+    total = 0.0
+    for cam, target in zip(self.cameras, self.targets):
+      with torch.enable_grad():
+        r = render_gaussians(self.scene(), cam, self.config, use_sh=True)
+        if r.points.num_visible == 0:
+          raise RuntimeError("No visible points")                     # trainer.py:507-509
+        loss = F.mse_loss(r.image.clamp(0, 1), target)
+        loss.backward()
+      with torch.no_grad():
+        self.state.add_rendering(r)                                    # point_state.py:34-50 (camera order)
+      total += float(loss.item())
+    self.opt.step()
+    with torch.no_grad():                                              # mlp_scene.py:236-237
+      self.params["rotation"].data = F.normalize(self.params["rotation"].data, dim=1)
+      self.params["log_scaling"].data.clamp_(min=-8, max=8)
+    self.step_idx += 1
+    self.log.losses.append(total / len(self.cameras))
+    self.log.num_points.append(self.num_points)
+    if self.densify_every and self.step_idx % self.densify_every == 0 and self.step_idx < self.total_steps:
+      self.densify_and_prune()
+    return self.log.losses[-1]
+
+  @torch.no_grad()
+  def densify_and_prune(self):
+    t = self.step_idx / self.total_steps
+    split_mask, prune_mask = find_split_prune_indexes(self.state, t, self.target_points, self.prune_rate,
+                                                      self.min_views, self.max_scale_px)
+    digest = hashlib.sha256(torch.cat([split_mask, prune_mask]).cpu().numpy().tobytes()).hexdigest()
+    self.log.mask_digests.append(digest)
+    keep_mask = ~(split_mask | prune_mask)
+    split_idx = split_mask.nonzero().squeeze(1)
+    rows = {n: p.data for n, p in self.params.items()}
+    splits = split_gaussians_uniform({n: t_[split_idx] for n, t_ in rows.items()}, k=2, random_axis=True,
+                                     generator=self.gen)
+    self.params = {n: torch.cat([rows[n][keep_mask], splits[n]]).contiguous().requires_grad_(True) for n in PARAM_NAMES}
+    self.state = PointState.new_zeros(self.num_points, self.device)   # target_controller.py:120-122
+    self._new_optimizer()                                             # optimizer state is re-created (harness)
+
+  def train(self, steps: int) -> TrainLog:
+    for _ in range(steps):
+      self.training_step()
+    return self.log

@@ -1,0 +1,65 @@
+"""BASELINE config c4 in miniature: a training loop over the HIP rasterizer with the reference's densify/prune
+arithmetic and a changing splat count (buffers re-sized every densify).  Checks that the loss goes down, the
+count follows the controller, every intermediate stays finite, and the whole run -- including the split/prune
+masks -- is bit-reproducible."""
+import pytest
+import torch
+
+import splat_trainer_amd as sta
+from splat_trainer_amd import synthetic
+from splat_trainer_amd.harness import MiniTrainer, split_gaussians_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=6000, w=160, h=120, ncam=3):
+  g, cams = synthetic.scene_b(n, w, h, sh_degree=1, seed=4, num_cameras=8, sigma_px=2.5)
+  dev = "cuda"
+  g = g.to(dev)
+  cams = [c.to(dev) for c in cams[:ncam]]
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  # targets: renders of a perturbed copy of the scene, so there is something to learn
+  torch.manual_seed(0)
+  gt = sta.Gaussians3D(g.position + 0.01 * torch.randn_like(g.position), g.rotation, g.log_scaling + 0.1,
+                       g.alpha_logit + 0.5, g.feature * 1.3)
+  with torch.no_grad():
+    targets = [sta.render_gaussians(gt, c, cfg, use_sh=True).image.clamp(0, 1) for c in cams]
+  return g, cams, targets, cfg
+
+
+def _run(steps=24):
+  g, cams, targets, cfg = _setup()
+  tr = MiniTrainer(g, cams, targets, cfg, lr=2e-3, densify_every=8, target_points=6600, min_views=2,
+                   total_steps=steps, seed=1)
+  log = tr.train(steps)
+  return tr, log
+
+
+def test_train_loop_with_densify_prune_is_reproducible():
+  tr, log = _run()
+  assert all(torch.isfinite(p).all() for p in tr.params.values())
+  assert len(log.mask_digests) == 2                                   # densify at its 8 and 16 (not at the last)
+  assert log.num_points[0] == 6000 and log.num_points[-1] != 6000 and 5500 < log.num_points[-1] <= 6700
+  assert sum(log.losses[-4:]) < sum(log.losses[:4])                   # it learns
+  tr2, log2 = _run()
+  assert log2.mask_digests == log.mask_digests                        # bit-reproducible densification
+  assert log2.losses == log.losses and log2.num_points == log.num_points
+  for n in tr.params:
+    assert torch.equal(tr.params[n], tr2.params[n]), n
+
+
+def test_split_gaussians_uniform_matches_reference_rule():
+  """split.py:87-113: two children at -/+0.7 sigma along one axis, that axis shrunk by 1/sqrt(2)."""
+  torch.manual_seed(0)
+  pts = dict(position=torch.randn(50, 3), log_scaling=torch.randn(50, 3) * 0.3, rotation=torch.randn(50, 4),
+             alpha_logit=torch.randn(50, 1), feature=torch.randn(50, 3, 4))
+  out = split_gaussians_uniform(pts, k=2, random_axis=False)
+  assert out["position"].shape == (100, 3) and out["feature"].shape == (100, 3, 4)
+  axis = torch.argmax(pts["log_scaling"], dim=1)
+  d = (out["position"][0::2] - out["position"][1::2]).norm(dim=1)
+  sigma = pts["log_scaling"].exp().gather(1, axis[:, None]).squeeze(1)
+  assert torch.allclose(d, 1.4 * sigma, rtol=1e-4)
+  mid = 0.5 * (out["position"][0::2] + out["position"][1::2])
+  assert torch.allclose(mid, pts["position"], atol=1e-5)
+  shrunk = out["log_scaling"][0::2].gather(1, axis[:, None]).squeeze(1)
+  assert torch.allclose(shrunk, pts["log_scaling"].gather(1, axis[:, None]).squeeze(1) - 0.5 * torch.log(torch.tensor(2.0)))

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restric
   dlogit[i] = ACC ? dlogit[i] + o.dlogit : o.dlogit;
 }
 
-template <int K>
+template <int K, bool JAC>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ sh, const float* __restrict__ pos,
                                                      const int64_t* __restrict__ idx, int64_t M,
                                                      const float* __restrict__ cam_pos, float* __restrict__ out,
@@ -122,52 +122,42 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
   if (m >= M) return;
   const int64_t i = idx[m];
   float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
-  float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+  const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+  const float x = dx * inv, y = dy * inv, z = dz * inv;
   float Y[K];
-  gsr_sh_basis<K>(dx * inv, dy * inv, dz * inv, Y);
+  gsr_sh_basis<K>(x, y, z, Y);
+  float dYx[K], dYy[K], dYz[K];
+  if (JAC) gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
   const float* row = sh + (int64_t)3 * K * i;
-  float c[3];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    float acc = 0.5f;
+    // one sweep over the coefficient row feeds both the colour and (JAC) its derivative wrt the view direction
+    float acc = 0.5f, gx = 0.f, gy = 0.f, gz = 0.f;
+    float w[K];
     if (K % 4 == 0) {
 #pragma unroll
       for (int k = 0; k < K; k += 4) {
-        float4 v = *reinterpret_cast<const float4*>(row + ch * K + k);
-        acc += v.x * Y[k] + v.y * Y[k + 1] + v.z * Y[k + 2] + v.w * Y[k + 3];
+        const float4 v = *reinterpret_cast<const float4*>(row + ch * K + k);
+        w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < K; ++k) acc += row[ch * K + k] * Y[k];
-    }
-    c[ch] = acc;
-  }
-  out[3 * m] = c[0]; out[3 * m + 1] = c[1]; out[3 * m + 2] = c[2];
-  if (jac != nullptr) {
-    // d colour_c / d position (3x3), through the view direction d = v/|v|: saved so that the backward pass
-    // does not have to stream the 12K-byte coefficient row again
-    float J[9];
-    if (K > 1) {
-      float dYx[K], dYy[K], dYz[K];
-      const float x = dx * inv, y = dy * inv, z = dz * inv;
-      gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
-        for (int k = 1; k < K; ++k) {
-          const float w = row[ch * K + k];
-          gx += w * dYx[k]; gy += w * dYy[k]; gz += w * dYz[k];
-        }
-        const float dot = gx * x + gy * y + gz * z;
-        J[3 * ch] = (gx - x * dot) * inv; J[3 * ch + 1] = (gy - y * dot) * inv; J[3 * ch + 2] = (gz - z * dot) * inv;
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) J[t] = 0.f;
+      for (int k = 0; k < K; ++k) w[k] = row[ch * K + k];
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) jac[9 * m + t] = J[t];
+    for (int k = 0; k < K; ++k) {
+      acc += w[k] * Y[k];
+      if (JAC && k > 0) { gx += w[k] * dYx[k]; gy += w[k] * dYy[k]; gz += w[k] * dYz[k]; }
+    }
+    out[3 * m + ch] = acc;
+    if (JAC) {
+      // d colour_ch / d position through d = v/|v|; saved (36 B per splat) so that the backward pass does not
+      // have to stream the 12K-byte coefficient row again
+      const float dot = gx * x + gy * y + gz * z;
+      jac[9 * m + 3 * ch] = (gx - x * dot) * inv;
+      jac[9 * m + 3 * ch + 1] = (gy - y * dot) * inv;
+      jac[9 * m + 3 * ch + 2] = (gz - z * dot) * inv;
+    }
   }
 }
 
@@ -342,10 +332,22 @@ int gsr_sh_forward(const float* sh_features, const float* positions, const int64
   if (!sh_features || !positions || !indexes || !camera_pos || !colors_out) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
   switch (K) {
-    case 1: sh_fwd_kernel<1><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
-    case 4: sh_fwd_kernel<4><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
-    case 9: sh_fwd_kernel<9><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
-    default: sh_fwd_kernel<16><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out); break;
+    case 1:
+      if (jacobian_out) sh_fwd_kernel<1, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
+      else sh_fwd_kernel<1, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      break;
+    case 4:
+      if (jacobian_out) sh_fwd_kernel<4, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
+      else sh_fwd_kernel<4, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      break;
+    case 9:
+      if (jacobian_out) sh_fwd_kernel<9, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
+      else sh_fwd_kernel<9, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      break;
+    default:
+      if (jacobian_out) sh_fwd_kernel<16, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
+      else sh_fwd_kernel<16, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      break;
   }
   GSR_CHECK_LAUNCH();
   return GSR_OK;

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_row_total_kernel(const uint32_t
   if (threadIdx.x == 0) digit_total[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(uint32_t* __restrict__ hist, uint32_t num_blocks,
+__global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(const uint32_t* __restrict__ hist,
+                                                                   uint32_t* __restrict__ offs, uint32_t num_blocks,
                                                                    const uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_carry;
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(uint32_t* __r
   __syncthreads();
   if (threadIdx.x == 0) s_carry = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
   __syncthreads();
-  uint32_t* row = hist + (size_t)d * num_blocks;
+  const uint32_t* row = hist + (size_t)d * num_blocks;
+  uint32_t* orow = offs + (size_t)d * num_blocks;
   for (uint32_t b0 = 0; b0 < num_blocks; b0 += RS_THREADS) {
     const uint32_t b = b0 + threadIdx.x;
     const uint32_t v = (b < num_blocks) ? row[b] : 0u;
@@ -211,29 +213,53 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(uint32_t* __r
       if (w < wave) wbase += c;
       total += c;
     }
-    if (b < num_blocks) row[b] = s_carry + wbase + incl - v;
+    if (b < num_blocks) orow[b] = s_carry + wbase + incl - v;
     __syncthreads();
     if (threadIdx.x == 0) s_carry += total;
     __syncthreads();
   }
 }
 
-template <bool TWO>
+// Stable scatter with LDS staging.  The block's elements are first placed, digit-bucket by digit-bucket, into an LDS
+// image (ballot-match ranks inside each wave, wave counts through LDS, running per-digit counts across rounds), then
+// written out in image order: consecutive threads write consecutive addresses inside each digit run, so the global
+// stores are coalesced segments instead of 4-byte singles.
+template <bool TWO, int ROUNDS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,   // null -> iota
                                                                 const uint32_t* __restrict__ vals2_in,
                                                                 uint32_t* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out,
                                                                 uint32_t* __restrict__ vals2_out, uint32_t n, int shift,
-                                                                uint32_t mask, int rounds,
+                                                                uint32_t mask, const uint32_t* __restrict__ counts,
                                                                 const uint32_t* __restrict__ offsets,
                                                                 uint32_t num_blocks) {
-  __shared__ uint32_t s_base[RS_BINS];        // next output slot of each digit for this block
+  constexpr int TILE = ROUNDS * RS_THREADS;
+  __shared__ uint32_t s_start[RS_BINS];       // first image slot of each digit
+  __shared__ uint32_t s_goff[RS_BINS];        // global slot of the digit's first element of this block
+  __shared__ uint32_t s_run[RS_BINS];         // elements of the digit placed by earlier rounds
   __shared__ uint32_t s_wcnt[4][RS_BINS];     // per-wave digit counts of the current round
-  const int wave = threadIdx.x >> 6;
-  s_base[threadIdx.x] = offsets[threadIdx.x * num_blocks + blockIdx.x];
-  const uint32_t base = blockIdx.x * (uint32_t)(rounds * RS_THREADS);
-  for (int r = 0; r < rounds; ++r) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_key[TILE];
+  __shared__ uint32_t s_val[TILE];
+  __shared__ uint32_t s_val2[TWO ? TILE : 1];
+  const int lane = gsr_lane(), wave = threadIdx.x >> 6;
+  {
+    const uint32_t c = counts[threadIdx.x * num_blocks + blockIdx.x];
+    s_goff[threadIdx.x] = offsets[threadIdx.x * num_blocks + blockIdx.x];
+    s_run[threadIdx.x] = 0;
+    const uint32_t incl = gsr_wave_scan_incl_u32(c);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (w < wave) wbase += s_wave[w];
+    s_start[threadIdx.x] = wbase + incl - c;
+  }
+  const uint32_t base = blockIdx.x * (uint32_t)TILE;
+  const uint32_t block_n = min((uint32_t)TILE, n - base);
+  for (int r = 0; r < ROUNDS; ++r) {
     const uint32_t round_base = base + r * RS_THREADS;
     if (round_base >= n) break;                               // uniform over the block
 #pragma unroll
@@ -248,8 +274,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
       if (TWO) val2 = vals2_in[idx];
       digit = (key >> shift) & mask;
     }
-    // lanes of this wave holding the same digit
-    uint64_t peers = __ballot(valid);
+    uint64_t peers = __ballot(valid);                          // lanes of this wave holding the same digit
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       uint64_t bit = __ballot((digit >> b) & 1u);
@@ -259,17 +284,25 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     if (valid && rank == 0) s_wcnt[wave][digit] = (uint32_t)__popcll(peers);
     __syncthreads();
     if (valid) {
-      uint32_t off = s_base[digit] + (uint32_t)rank;
+      uint32_t slot = s_start[digit] + s_run[digit] + (uint32_t)rank;
 #pragma unroll
       for (int w = 0; w < 4; ++w)
-        if (w < wave) off += s_wcnt[w][digit];
-      keys_out[off] = key;
-      vals_out[off] = val;
-      if (TWO) vals2_out[off] = val2;
+        if (w < wave) slot += s_wcnt[w][digit];
+      s_key[slot] = key;
+      s_val[slot] = val;
+      if (TWO) s_val2[slot] = val2;
     }
     __syncthreads();
-    s_base[threadIdx.x] += s_wcnt[0][threadIdx.x] + s_wcnt[1][threadIdx.x] + s_wcnt[2][threadIdx.x] + s_wcnt[3][threadIdx.x];
-    __syncthreads();
+    s_run[threadIdx.x] += s_wcnt[0][threadIdx.x] + s_wcnt[1][threadIdx.x] + s_wcnt[2][threadIdx.x] + s_wcnt[3][threadIdx.x];
+  }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < block_n; e += RS_THREADS) {
+    const uint32_t key = s_key[e];
+    const uint32_t d = (key >> shift) & mask;
+    const uint32_t dst = s_goff[d] + (e - s_start[d]);
+    keys_out[dst] = key;
+    vals_out[dst] = s_val[e];
+    if (TWO) vals2_out[dst] = s_val2[e];
   }
 }
 
@@ -278,7 +311,7 @@ size_t sort_ws_bytes(int64_t n) {
   const uint64_t tile = (uint64_t)rs_rounds_for(n) * RS_THREADS;
   const uint64_t nb = ((uint64_t)n + tile - 1) / tile;
   const size_t hist = ((nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
-  return hist + 5 * RS_BINS * sizeof(uint32_t) + 256;        // + digit totals of up to 5 passes
+  return 2 * hist + 5 * RS_BINS * sizeof(uint32_t) + 256;    // counts + offsets tables + digit totals
 }
 
 int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
@@ -294,7 +327,8 @@ int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* k
   const uint32_t nb = (uint32_t)((n + tile - 1) / tile);
   uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
   const size_t hist_bytes = (((size_t)nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
-  uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + hist_bytes);
+  uint32_t* offs = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + hist_bytes);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + 2 * hist_bytes);
   int passes = (end_bit - begin_bit + 7) / 8;
   if (passes < 1) passes = 1;
   if (passes > 5) return GSR_ERR_INVALID_ARGUMENT;
@@ -312,14 +346,14 @@ int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* k
     GSR_CHECK_LAUNCH();
     rs_row_total_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
     GSR_CHECK_LAUNCH();
-    rs_digit_scan_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
+    rs_digit_scan_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, offs, nb, tot);
     GSR_CHECK_LAUNCH();
-    if (two)
-      rs_scatter_kernel<true><<<nb, RS_THREADS, 0, stream>>>(kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask,
-                                                            rounds, hist, nb);
-    else
-      rs_scatter_kernel<false><<<nb, RS_THREADS, 0, stream>>>(kin, vin, nullptr, kout, vout, nullptr, (uint32_t)n, bit,
-                                                             mask, rounds, hist, nb);
+#define GSR_RS_SCATTER(TWO_, R_)                                                                                     \
+  rs_scatter_kernel<TWO_, R_><<<nb, RS_THREADS, 0, stream>>>(kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, \
+                                                             hist, offs, nb)
+    if (two) { if (rounds == 4) GSR_RS_SCATTER(true, 4); else GSR_RS_SCATTER(true, 16); }
+    else     { if (rounds == 4) GSR_RS_SCATTER(false, 4); else GSR_RS_SCATTER(false, 16); }
+#undef GSR_RS_SCATTER
     GSR_CHECK_LAUNCH();
     where ^= 1;
     if (where == 1) { kin = keys_b; vin = vals_b; v2in = vals2_b; kout = keys_a; vout = vals_a; v2out = vals2_a; }

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict_
     for (int tx = e.x0; tx < e.x1; ++tx)
       if (gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty)) {
         keys[o] = (uint32_t)(ty * tiles_x + tx);
-        inst2rank[o] = (uint32_t)k;
+        // depth rank in the low 30 bits, which tile halves the support reaches in the top 2
+        inst2rank[o] = (uint32_t)k | (gsr_tile_half_mask(u, v, A, B, C, e.qmax, tx, ty) << 30);
         ++o;
       }
 }
@@ -208,7 +209,7 @@ int gsr_tile_count(const float* gaussians2d, const float* depth, const float* fe
 int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
                   const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (M < 0 || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M < 0 || M >= (1ll << 30) || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
   if (!rec || !offsets || !keys_out || !inst2rank_out) return GSR_ERR_INVALID_ARGUMENT;

@@ -51,18 +51,21 @@ __device__ __forceinline__ v2f eval_G2(v2f q) {     // exp(-q/2) = 2^(q * -0.5*l
 
 struct Splat {            // one depth-ordered record, wave-uniform (lives in SGPRs)
   float u, v, A, B, C, op, depth, f0, f1, f2;
+  uint32_t halves;        // bit h set: the splat's support reaches tile half h (from K4 emit)
 };
 
 // i is wave-uniform: the index load and the three 16-byte record loads become scalar-cache loads.
 template <int C>
 __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const uint32_t* __restrict__ sorted_rank,
                                             uint32_t i) {
-  const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorted_rank[i]);
+  const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorted_rank[i]);
+  const uint32_t k = packed & 0x3FFFFFFFu;
   const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_REC_FLOATS * k);
   const float4 r0 = r[0], r1 = r[1];
   Splat s;
   s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.depth = r1.z; s.f0 = r1.w;
   s.f1 = 0.f; s.f2 = 0.f;
+  s.halves = packed >> 30;
   if (C > 1) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; }
   return s;
 }
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
           v2f wsum2 = GSR_V2(0.f);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
+            if (!(s.halves & (1u << h))) continue;                        // scalar test: support misses this half
             const float dy = h ? dya + 8.f : dya;
             const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
             const bool in0 = T2[h].x >= rp.T_eps && q.x <= rp.q_max;
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
       v2f df2[3] = {du2, du2, du2};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        if (!(s.halves & (1u << h))) continue;                            // scalar test: support misses this half
         const float dy = h ? dya + 8.f : dya;
         const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
         const bool in0 = pos < lastc[2 * h] && q.x <= rp.q_max;

@@ -336,14 +336,28 @@ GSR_HD float gsr_edge_min_q(float Kf, float Bc, float Kv, float d_fixed, float l
   return Kf * d_fixed * d_fixed + 2.f * Bc * d_fixed * d + Kv * d * d;
 }
 
-// Does the ellipse {q <= qmax} reach the rectangle of pixel centres of tile (tx, ty)?
-GSR_HD bool gsr_tile_hit(float u, float v, float A, float B, float C, float qmax, int tx, int ty) {
-  float rx0 = 16.f * tx + 0.5f - u, rx1 = 16.f * tx + 15.5f - u;   // rectangle relative to the mean
-  float ry0 = 16.f * ty + 0.5f - v, ry1 = 16.f * ty + 15.5f - v;
+// Does the ellipse {q <= qmax} reach the rectangle [rx0,rx1] x [ry0,ry1] (given relative to the mean)?
+GSR_HD bool gsr_rect_hit(float A, float B, float C, float qmax, float rx0, float rx1, float ry0, float ry1) {
   if (rx0 <= 0.f && rx1 >= 0.f && ry0 <= 0.f && ry1 >= 0.f) return true;
   float m = gsr_edge_min_q(A, B, C, rx0, ry0, ry1);
   m = fminf(m, gsr_edge_min_q(A, B, C, rx1, ry0, ry1));
   m = fminf(m, gsr_edge_min_q(C, B, A, ry0, rx0, rx1));
   m = fminf(m, gsr_edge_min_q(C, B, A, ry1, rx0, rx1));
   return m <= qmax;
+}
+
+// ... the rectangle of pixel centres of tile (tx, ty)?
+GSR_HD bool gsr_tile_hit(float u, float v, float A, float B, float C, float qmax, int tx, int ty) {
+  return gsr_rect_hit(A, B, C, qmax, 16.f * tx + 0.5f - u, 16.f * tx + 15.5f - u, 16.f * ty + 0.5f - v,
+                      16.f * ty + 15.5f - v);
+}
+
+// ... the pixel centres of the upper (bit 0: rows 0-7) / lower (bit 1: rows 8-15) half of tile (tx, ty)?
+// The composite kernels evaluate a tile half as one unit and skip a half whose bit is clear.
+GSR_HD unsigned gsr_tile_half_mask(float u, float v, float A, float B, float C, float qmax, int tx, int ty) {
+  const float rx0 = 16.f * tx + 0.5f - u, rx1 = 16.f * tx + 15.5f - u;
+  const float ry = 16.f * ty + 0.5f - v;
+  unsigned m = gsr_rect_hit(A, B, C, qmax, rx0, rx1, ry, ry + 7.f) ? 1u : 0u;
+  m |= gsr_rect_hit(A, B, C, qmax, rx0, rx1, ry + 8.f, ry + 15.f) ? 2u : 0u;
+  return m;
 }

@@ -114,6 +114,8 @@ def main():
   ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--collective", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
+  ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                  help="nccl = RCCL over xGMI (default); gloo only for rehearsing the multi-rank path on one GPU")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,11 +125,16 @@ def main():
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU: the rasterizer path has no CPU fallback")
+  if os.environ.get("BENCH_SHARE_GPU") == "1":      # rehearsal only: every rank on device 0 (needs --backend gloo)
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
+    if args.backend == "nccl":
+      dist.init_process_group("nccl", device_id=dev)
+    else:
+      dist.init_process_group("gloo")
 
   import splat_trainer_amd as sta
   from splat_trainer_amd import renderer

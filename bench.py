@@ -113,7 +113,9 @@ def main():
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--collective", default="reduce_scatter", choices=["reduce_scatter", "all_reduce"])
+  ap.add_argument("--collective", default="all_reduce", choices=["reduce_scatter", "all_reduce"],
+                  help="one fused all_reduce of the flat gradient buffer (default: RCCL spreads it over all xGMI links "
+                       "with several channels), or reduce_scatter + all_gather of the same buffer")
   ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                   help="nccl = RCCL over xGMI (default); gloo only for rehearsing the multi-rank path on one GPU")
   args = ap.parse_args()

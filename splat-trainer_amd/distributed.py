@@ -6,12 +6,14 @@ The reference has no distributed code; the seam is its sequential per-camera loo
 accumulation, splat_trainer/trainer/trainer.py:500-514 (``evaluate_backward_with``).  Parameters (and
 optimizer state) are fully replicated; a camera's render is not split across GPUs.
 
-Collective choice.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of the
-708 MB fp32 gradient buffer of the 3M-Gaussian/SH3 config is bound by one link, while reduce-scatter +
-all-gather moves 1/world of the buffer over every link at once.  All gradients are therefore packed
-into one contiguous fp32 buffer (padded to a multiple of world_size) and reduced with
-``reduce_scatter_tensor`` + ``all_gather_into_tensor``; ``mode="all_reduce"`` keeps the single-call form
-(the only one gloo supports for CPU tests).
+Collective choice.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so what matters is that the
+message is ONE large contiguous buffer that RCCL can split over all links/channels at once, not many
+per-tensor calls each bound by launch latency: all gradients are packed into one contiguous fp32 buffer
+(padded to a multiple of world_size; 120 MB at 500k splats/SH3, 708 MB at 3M).  ``mode="all_reduce"``
+(default of bench.py) issues a single fused all-reduce; ``mode="reduce_scatter"`` issues
+``reduce_scatter_tensor`` + ``all_gather_into_tensor`` on the same buffer (the form a sharded optimizer
+step would slot between; gloo, used by the CPU tests, falls back to all_reduce).  Neither could be timed in
+this build environment (one GPU); both are kept selectable.
 """
 from __future__ import annotations
 
@@ -55,7 +57,7 @@ class GradBucket:
   def zero(self):
     self.flat.zero_()
 
-  def all_reduce(self, group=None, mode: str = "reduce_scatter"):
+  def all_reduce(self, group=None, mode: str = "all_reduce"):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
       return
     ws = dist.get_world_size(group)

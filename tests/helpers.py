@@ -19,14 +19,22 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
   return (a - b).abs().max().item() / scale
 
 
+def frac_above(a: torch.Tensor, b: torch.Tensor, tol: float) -> float:
+  """Fraction of entries whose error exceeds tol x the reference's max magnitude."""
+  a, b = a.detach().double().cpu(), b.detach().double().cpu()
+  scale = max(b.abs().max().item(), 1e-30)
+  return ((a - b).abs() > tol * scale).double().mean().item()
+
+
 def small_scene(n=400, w=64, h=48, sh_degree=0, seed=3, sigma_px=3.0):
   import splat_trainer_amd.synthetic as syn
   return syn.scene_a(n, w, h, sh_degree=sh_degree, seed=seed, sigma_px=sigma_px)
 
 
-def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, dtype=torch.float32,
+def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, dtype=torch.float64,
                             loss_scale=1.0):
-  """Oracle forward + MSE loss + autograd backward + analytic per-point heuristics."""
+  """Oracle forward + MSE loss + autograd backward + analytic per-point heuristics.  fp64 by default, so that
+  the comparison measures the fp32 HIP path's error alone (not HIP error + the oracle's own fp32 rounding)."""
   pos = g.position.clone().to(dtype).requires_grad_(True)
   ls = g.log_scaling.clone().to(dtype).requires_grad_(True)
   rot = g.rotation.clone().to(dtype).requires_grad_(True)

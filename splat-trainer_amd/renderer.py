@@ -77,8 +77,8 @@ def _require_device(*tensors: torch.Tensor):
     if not t.is_cuda:
       raise _lib.GsplatHipError(
           "the rasterizer path runs only on a HIP device (got a CPU tensor); there is no CPU fallback")
-    if t.dtype not in (torch.float32, torch.int64, torch.int32):
-      raise TypeError(f"unsupported dtype {t.dtype}; the path computes in float32")
+    if t.dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.int64, torch.int32):
+      raise TypeError(f"unsupported dtype {t.dtype}; the path computes in float32 (half inputs are widened)")
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -140,6 +140,7 @@ class _ProjectFn(torch.autograd.Function):
     ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
     ctx.params = params
     ctx.grad_out = grad_out
+    ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype)
     return g2d, depth
 
   @staticmethod
@@ -163,7 +164,8 @@ class _ProjectFn(torch.autograd.Function):
                                           _stream()), "gsr_project_backward")
     if go is not None:
       return None, None, None, None, None, None, None, None, None
-    return d_pos, d_ls, d_rot, d_al, None, None, None, None, None
+    dt = ctx.in_dtypes
+    return d_pos.to(dt[0]), d_ls.to(dt[1]), d_rot.to(dt[2]), d_al.to(dt[3]), None, None, None, None, None
 
 
 def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
@@ -290,6 +292,7 @@ class _RasterFn(torch.autograd.Function):
     g, f, d = _f32c(g2d), _f32c(feats), _f32c(depth).reshape(-1)
     image = _bin_and_composite(g, f, d, st, need_vis_partial=st.compute_visibility or st.needs_grad)
     ctx.st = st
+    ctx.in_dtypes = (g2d.dtype, feats.dtype)      # e.g. fp16 colours from an autocast MLP (mlp_scene.py:362)
     return image
 
   @staticmethod
@@ -321,7 +324,7 @@ class _RasterFn(torch.autograd.Function):
                                           _ptr(st.order), st.M, st.C, _ptr(d_g2d), _ptr(d_feat),
                                           _ptr(st.prune_cost), _ptr(st.split_score), stream),
                  "gsr_reduce_gradients")
-    return d_g2d, d_feat, None, None
+    return d_g2d.to(ctx.in_dtypes[0]), d_feat.to(ctx.in_dtypes[1]), None, None
 
 
 def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features: torch.Tensor,

@@ -40,6 +40,7 @@ class _SHFn(torch.autograd.Function):
     ctx.save_for_backward(sh, pos, idx, cam)
     ctx.jac = jac
     ctx.grad_out = grad_out
+    ctx.in_dtypes = (sh_features.dtype, positions.dtype)
     return out
 
   @staticmethod
@@ -62,7 +63,8 @@ class _SHFn(torch.autograd.Function):
                  "gsr_sh_backward")
     if go is not None:
       return None, None, None, None, None, None
-    return d_sh, d_pos, None, None, None, None
+    return (d_sh.to(ctx.in_dtypes[0]), d_pos.to(ctx.in_dtypes[1]) if d_pos is not None else None,
+            None, None, None, None)
 
 
 def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: torch.Tensor,

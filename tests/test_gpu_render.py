@@ -294,3 +294,20 @@ def test_eval_mode_keeps_no_backward_state():
   d = r.detach()
   assert d.points.visibility.shape == r.points.idx.shape and d.points.num_visible > 0
   assert (r.median_ndc_image >= 0).all() and (r.median_ndc_image <= 1).all()
+
+
+def test_half_precision_colours_from_autocast_mlp():
+  """The reference evaluates its colour MLP under fp16 autocast (mlp_scene.py:362) and hands the result to
+  render_projected: the path computes in fp32 and returns the feature gradient in the input's dtype."""
+  g, cam = small_scene(300, 64, 64, sh_degree=0, seed=3)
+  gd = sta.Gaussians3D(*(t.cuda() for t in (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+  g2d, depth, idx = sta.project_to_image(gd, cam.to("cuda"), CFG)
+  f32 = torch.rand(idx.shape[0], 3, device="cuda")
+  f16 = f32.half().requires_grad_(True)
+  fref = f16.detach().float().requires_grad_(True)
+  ra = sta.render_projected(idx, g2d, f16, depth, cam.to("cuda"), CFG)
+  rb = sta.render_projected(idx, g2d, fref, depth, cam.to("cuda"), CFG)
+  assert ra.image.dtype == torch.float32 and torch.equal(ra.image, rb.image)
+  ra.image.sum().backward(); rb.image.sum().backward()
+  assert f16.grad.dtype == torch.float16
+  assert torch.allclose(f16.grad.float(), fref.grad, rtol=2e-3, atol=1e-3)

@@ -1,0 +1,110 @@
+"""The reference's own call pattern around the boundary, restated with this build's imports
+(splat_trainer/scene/mlp_scene.py:410-427 render, :268-288 reg_loss, :241-244 add_rendering;
+trainer.py:500-514 evaluate_backward_with; controller/point_state.py:34-50): project_to_image ->
+colour MLP on the gathered features (fp16 autocast) -> render_projected -> dataclasses.replace -> losses that
+use rendering.points.visible.{opacity, depths} differentiably -> loss.backward() -> per-point outputs read
+AFTER backward.  Every parameter gradient (Gaussian parameters AND the MLP weights) is compared with the same
+flow run through the CPU oracle."""
+from dataclasses import replace
+
+import pytest
+import torch
+import torch.nn as nn
+
+import splat_trainer_amd as sta
+from helpers import oracle, rel_err, small_scene
+from splat_trainer_amd.controller_math import PointState
+
+pytestmark = pytest.mark.gpu
+
+
+def saturate(t, gain=6.0, k=1.0):                    # util/misc.py:68-69 (golden-tested in test_oracle_golden)
+  return (1 - 1 / torch.exp(gain * t)).pow(k)
+
+
+class TinyColorModel(nn.Module):
+  """Stand-in for scene/color_model.py: per-point feature (+ view direction) -> 3 colour channels."""
+
+  def __init__(self, nfeat):
+    super().__init__()
+    torch.manual_seed(0)
+    self.net = nn.Sequential(nn.Linear(nfeat + 3, 16), nn.SiLU(), nn.Linear(16, 3))
+
+  def forward(self, feature, position, cam_pos):
+    d = torch.nn.functional.normalize(position - cam_pos, dim=1)
+    return torch.sigmoid(self.net(torch.cat([feature, d], dim=1)))
+
+
+def reg_loss(points_visible, log_scaling_all):
+  """mlp_scene.py:268-288 (scale / opacity / aspect terms, visibility-weighted)."""
+  log_scale = log_scaling_all[points_visible.idx]
+  scale = torch.exp(log_scale)
+  norm_scale = scale.pow(2).sum(1) / points_visible.depths.pow(2).squeeze(-1)
+  opacity_term = saturate(points_visible.opacity, gain=4.0, k=2.0) * norm_scale
+  aspect = scale.max(1).values / scale.min(1).values
+  w = points_visible.visibility
+  return 0.1 * (norm_scale * w).mean() + 0.1 * (opacity_term * w).mean() + 0.01 * (aspect * w).mean()
+
+
+@pytest.mark.parametrize("autocast,tol", [(False, 2e-4), (True, 3e-2)])
+def test_reference_call_pattern_matches_oracle_flow(autocast, tol):
+  """autocast=False isolates the rasterizer (tight tolerance); autocast=True is the reference's fp16 colour MLP,
+  whose half-precision rounding (not the rasterizer) sets the error level."""
+  g, cam = small_scene(600, 96, 72, sh_degree=0, seed=21, sigma_px=3.0)
+  nfeat = 8
+  torch.manual_seed(1)
+  point_feature = torch.randn(600, nfeat)
+  target = torch.rand(72, 96, 3)
+  cfg_opts = dict(antialias=False, compute_visibility=True, compute_point_heuristic=True, blur_cov=0.3)   # trainer.py:305-310
+
+  # ---------------- HIP path, written the way MLPScene.render is
+  dev = "cuda"
+  params = {n: getattr(g, n).clone().to(dev).requires_grad_(True) for n in ("position", "rotation", "log_scaling", "alpha_logit")}
+  feature = point_feature.clone().to(dev).requires_grad_(True)
+  model = TinyColorModel(nfeat).to(dev)
+  camd = cam.to(dev)
+  options = dict(cfg_opts)
+  config = sta.pop_raster_config(options)                                             # scene/util.py:11-22
+  gaussians = sta.Gaussians3D(feature=feature, **params)
+  with torch.enable_grad():
+    gaussians2d, depth, indexes = sta.project_to_image(gaussians, camd, config)     # mlp_scene.py:415
+    with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=autocast):   # mlp_scene.py:362
+      colors = model(feature[indexes], params["position"][indexes], camd.camera_position)
+    rendering = sta.render_projected(indexes, gaussians2d, colors, depth, camd, config, **options)   # :418
+    rendering = replace(rendering, points=rendering.points.replace(attributes=colors),
+                        image=rendering.image[..., :3].clamp(0, 1))                 # :422-424
+    assert rendering.points.num_visible > 0                                         # trainer.py:507
+    loss = torch.nn.functional.mse_loss(rendering.image, target.to(dev)) + \
+        torch.nn.functional.l1_loss(rendering.image, target.to(dev)) + reg_loss(rendering.points.visible, params["log_scaling"])
+    loss.backward()                                                                  # trainer.py:512
+  state = PointState.new_zeros(600, dev)
+  state.add_rendering(rendering)                                                     # point_state.py:34-50, after backward
+  assert state.split_score.abs().sum() > 0 and state.prune_cost.abs().sum() > 0 and state.points_in_view.sum() > 0
+
+  # ---------------- the same flow through the oracle (fp64, CPU)
+  op = {n: getattr(g, n).clone().double().requires_grad_(True) for n in params}
+  ofeature = point_feature.clone().double().requires_grad_(True)
+  omodel = TinyColorModel(nfeat).double()
+  T, proj = cam.T_camera_world.double(), cam.projection.double()
+  oidx = oracle.frustum_cull(op["position"], T, proj, cam.image_size, cam.near_plane, cam.far_plane, 48)
+  og2d, odepth, oss = oracle.project(op["position"], op["log_scaling"], op["rotation"], op["alpha_logit"], oidx, T, proj, config)
+  ocolors = omodel(ofeature[oidx], op["position"][oidx], cam.camera_position.double())
+  out = oracle.rasterize(og2d, odepth, ocolors, cam.image_size, config)
+  oimage = out.image.clamp(0, 1)
+  vis_rows = (out.visibility > 0).nonzero().squeeze(1)
+
+  class V:                                                                           # points.visible view
+    idx, depths, opacity, visibility = oidx[vis_rows], odepth[vis_rows], og2d[vis_rows, 5], out.visibility[vis_rows]
+  oloss = torch.nn.functional.mse_loss(oimage, target.double()) + torch.nn.functional.l1_loss(oimage, target.double()) + \
+      reg_loss(V, op["log_scaling"])
+  oloss.backward()
+
+  assert torch.equal(indexes.cpu(), oidx)
+  assert abs(loss.item() - oloss.item()) < max(tol, 1e-5) * abs(oloss.item())
+  for n in params:
+    assert rel_err(params[n].grad, op[n].grad) < tol, (n, rel_err(params[n].grad, op[n].grad))
+  assert rel_err(feature.grad, ofeature.grad) < tol
+  for (na, pa), (nb, pb) in zip(model.named_parameters(), omodel.named_parameters()):
+    assert rel_err(pa.grad, pb.grad) < tol, na
+  # the alpha_logit gradient has a component that arrives only through points.visible.opacity (reg_loss)
+  assert params["alpha_logit"].grad.abs().max() > 0

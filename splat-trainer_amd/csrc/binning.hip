@@ -142,11 +142,12 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
     const bool mine = threadIdx.x < m;
     const float v = mine ? vis_partial[c + threadIdx.x] : 0.f;
     s_vis[threadIdx.x] = v;
-    // slots never written by the backward pass (vis == 0) hold garbage: copied but never summed
+    __syncthreads();
+    // slots never written by the backward pass (vis == 0) hold garbage: neither fetched nor summed
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const uint32_t f = threadIdx.x + t * CH;                 // float4 index inside the chunk
-      if (f < 3 * m) s_part[f] = src[(size_t)3 * c + f];
+      if (f < 3 * m && s_vis[f / 3] > 0.f) s_part[f] = src[(size_t)3 * c + f];
     }
     __syncthreads();
     const uint32_t j0 = max(b, c), j1 = min(b + n, c + m);

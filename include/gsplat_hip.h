@@ -55,7 +55,7 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 4) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 5) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -81,11 +81,13 @@ int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_wor
                      int64_t* indexes_out, uint32_t* count_dev, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2 3D->2D projection forward / backward  (project_to_image, second half) --------------------------- */
-/* gaussians2d_out: [M,6] = u v A B C opacity; depth_out: [M]. */
+/* gaussians2d_out: [M,6] = u v A B C opacity; depth_out: [M].  count_dev (may be NULL): device word holding the
+ * true number of valid entries of ``indexes`` (<= M); lets the call be enqueued right behind gsr_frustum_cull,
+ * before the host has read the count back. */
 int gsr_project_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                         const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
-                        float* depth_out, void* stream);
+                        float* depth_out, const uint32_t* count_dev, void* stream);
 /* Rows ``indexes`` of the N-sized gradient tensors are written (accumulate = 0: other rows untouched, pass
  * zeros) or added to (accumulate = 1: "+=" straight into the caller's .grad buffers; rows are unique, no atomics). */
 int gsr_project_backward(const float* position, const float* log_scaling, const float* rotation_xyzw,

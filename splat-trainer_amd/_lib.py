@@ -11,7 +11,7 @@ import threading
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GsrRasterParamsC(C.Structure):
@@ -43,7 +43,7 @@ PROTOTYPES = {
     "gsr_sort_pairs2_u32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p]),
     "gsr_cull_workspace_bytes": (_sz, [_i64]),
     "gsr_frustum_cull": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _sz, _p]),
-    "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p]),
+    "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p]),
     "gsr_project_backward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     "gsr_sh_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p]),

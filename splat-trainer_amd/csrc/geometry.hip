@@ -59,9 +59,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const float* __restric
                                                           const int64_t* __restrict__ idx, int64_t M,
                                                           const float* __restrict__ Tcw, const float* __restrict__ proj,
                                                           GsrRasterParams rp, float* __restrict__ g2d,
-                                                          float* __restrict__ depth) {
+                                                          float* __restrict__ depth,
+                                                          const uint32_t* __restrict__ count_dev) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+  // M is an upper bound when count_dev is given: the true count is still on the device (K1 just produced it)
+  if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
   const GsrCam cam = gsr_load_cam(Tcw, proj);
   const int64_t i = idx[m];
   float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
@@ -237,7 +239,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 4; }
+int gsr_abi_version(void) { return 5; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -284,7 +286,7 @@ int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_wor
 int gsr_project_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                         const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
-                        float* depth_out, void* stream_) {
+                        float* depth_out, const uint32_t* count_dev, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
@@ -293,7 +295,7 @@ int gsr_project_forward(const float* position, const float* log_scaling, const f
     return GSR_ERR_INVALID_ARGUMENT;
   project_fwd_kernel<<<grid_for(M, 256), 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
                                                           T_camera_world, projection, to_params(params_host),
-                                                          gaussians2d_out, depth_out);
+                                                          gaussians2d_out, depth_out, count_dev);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

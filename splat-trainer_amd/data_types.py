@@ -68,9 +68,13 @@ class CameraParams:
 
   @property
   def camera_position(self) -> torch.Tensor:
-    R = self.T_camera_world[:3, :3]
-    t = self.T_camera_world[:3, 3]
-    return -(R.t() @ t)
+    cached = self.__dict__.get("_camera_position")       # the pose is immutable (frozen dataclass): compute once
+    if cached is None:
+      R = self.T_camera_world[:3, :3]
+      t = self.T_camera_world[:3, 3]
+      cached = -(R.t() @ t)
+      object.__setattr__(self, "_camera_position", cached)
+    return cached
 
   @property
   def focal_length(self) -> torch.Tensor:

@@ -127,24 +127,39 @@ class GradOut:
 
 
 class _ProjectFn(torch.autograd.Function):
+  """K1 + K2 as one autograd node.  The projection kernel is enqueued right behind the cull with the visible
+  count still on the device, so the GPU keeps working while the host reads the count back (the one unavoidable
+  sync: the size of ``indexes`` is data dependent)."""
+
   @staticmethod
-  def forward(ctx, position, log_scaling, rotation, alpha_logit, indexes, T, proj, params, grad_out):
+  def forward(ctx, position, log_scaling, rotation, alpha_logit, T, proj, cull_args, params, grad_out):
     lib = _lib.load()
     pos, ls, rot, al = _f32c(position), _f32c(log_scaling), _f32c(rotation), _f32c(alpha_logit)
-    M = indexes.shape[0]
-    g2d = torch.empty(M, 6, dtype=torch.float32, device=pos.device)
-    depth = torch.empty(M, 1, dtype=torch.float32, device=pos.device)
-    _lib.check(lib.gsr_project_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M, _ptr(T),
-                                       _ptr(proj), C.byref(params), _ptr(g2d), _ptr(depth), _stream()),
-               "gsr_project_forward")
+    N, dev = pos.shape[0], pos.device
+    W, H, near, far, margin = cull_args
+    stream = _stream()
+    indexes_full = torch.empty(N, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.gsr_cull_workspace_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    g2d_full = torch.empty(N, 6, dtype=torch.float32, device=dev)
+    depth_full = torch.empty(N, 1, dtype=torch.float32, device=dev)
+    _lib.check(lib.gsr_frustum_cull(_ptr(pos), N, _ptr(T), _ptr(proj), W, H, near, far, margin, _ptr(indexes_full),
+                                    _ptr(count), _ptr(ws), ws_bytes, stream), "gsr_frustum_cull")
+    _lib.check(lib.gsr_project_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes_full), N, _ptr(T),
+                                       _ptr(proj), C.byref(params), _ptr(g2d_full), _ptr(depth_full), _ptr(count),
+                                       stream), "gsr_project_forward")
+    M = int(count.item())          # host sync #1 (K2 is already running)
+    indexes, g2d, depth = indexes_full[:M], g2d_full[:M], depth_full[:M]
     ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
     ctx.params = params
     ctx.grad_out = grad_out
     ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype)
-    return g2d, depth
+    ctx.mark_non_differentiable(indexes)
+    return g2d, depth, indexes
 
   @staticmethod
-  def backward(ctx, d_g2d, d_depth):
+  def backward(ctx, d_g2d, d_depth, _d_indexes):
     lib = _lib.load()
     pos, ls, rot, al, indexes, T, proj = ctx.saved_tensors
     M, N = indexes.shape[0], pos.shape[0]
@@ -174,12 +189,14 @@ def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config
   ``indexes (M,) int64`` (ascending).  Differentiable wrt position / log_scaling / rotation /
   alpha_logit; gradients land in N-sized tensors, zero outside ``indexes``."""
   _require_device(gaussians.position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit)
-  indexes = frustum_cull(gaussians.position, camera_params, config)
   T = _f32c(camera_params.T_camera_world)
   proj = _f32c(camera_params.projection)
   params = _lib.raster_params(config)
-  g2d, depth = _ProjectFn.apply(gaussians.position, gaussians.log_scaling, gaussians.rotation,
-                                gaussians.alpha_logit, indexes, T, proj, params, grad_out)
+  W, H = camera_params.image_size
+  cull_args = (int(W), int(H), float(camera_params.near_plane), float(camera_params.far_plane),
+               float(config.margin_tiles * config.tile_size))
+  g2d, depth, indexes = _ProjectFn.apply(gaussians.position, gaussians.log_scaling, gaussians.rotation,
+                                         gaussians.alpha_logit, T, proj, cull_args, params, grad_out)
   return g2d, depth, indexes
 
 

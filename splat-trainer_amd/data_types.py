@@ -20,7 +20,7 @@ class RasterConfig:
   and ``compute_point_heuristic`` (trainer.py:305-310, mlp_scene.py:373); every keyword that
   names a field here is routed into the config by ``pop_raster_config`` (scene/util.py:11-22).
   """
-  tile_size: int = 16                 # pixels per tile side (one wave64 owns a tile, 2x2 px per lane)
+  tile_size: int = 16                 # pixels per tile side (one wave64 owns a tile, 4 px per lane)
   margin_tiles: int = 3               # frustum-cull margin around the image, in tiles
   alpha_threshold: float = 1.0 / 255.0
   clamp_max_alpha: float = 0.99

@@ -54,6 +54,20 @@ struct Splat {            // one depth-ordered record, wave-uniform (lives in SG
   uint32_t halves;        // bit h set: the splat's support reaches tile half h (from K4 emit)
 };
 
+// packed (rank | half mask << 30) is wave-uniform: the three 16-byte record loads become scalar-cache loads.
+template <int C>
+__device__ __forceinline__ Splat load_splat_packed(const float* __restrict__ rec, uint32_t packed) {
+  const uint32_t k = packed & 0x3FFFFFFFu;
+  const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_REC_FLOATS * k);
+  const float4 r0 = r[0], r1 = r[1];
+  Splat s;
+  s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.depth = r1.z; s.f0 = r1.w;
+  s.f1 = 0.f; s.f2 = 0.f;
+  s.halves = packed >> 30;
+  if (C > 1) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; }
+  return s;
+}
+
 // i is wave-uniform: the index load and the three 16-byte record loads become scalar-cache loads.
 template <int C>
 __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const uint32_t* __restrict__ sorted_rank,
@@ -234,12 +248,17 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
   for (int cbase = ((tile_last - 1) >> 6) << 6; cbase >= 0; cbase -= 64) {
     const int n = min(64, tile_last - cbase);
     // pairs that touched no pixel in the forward pass are skipped without evaluating anything
-    const float pv = (lane < n) ? pair_vis[start + (uint32_t)cbase + (uint32_t)lane] : 0.f;
+    // one coalesced vector load per 64 pairs for the skip flags, the packed ranks and the slot ids; a pair's
+    // values are then broadcast with v_readlane (no dependent index load in front of the record fetch)
+    const uint32_t li = start + (uint32_t)cbase + (uint32_t)lane;
+    const float pv = (lane < n) ? pair_vis[li] : 0.f;
+    const int my_rank = (lane < n) ? (int)sorted_rank[li] : 0;
+    const int my_inst = (lane < n) ? (int)sorted_inst[li] : 0;
     uint64_t flags = __ballot(pv > 0.f);
     if (flags == 0ull) continue;
     int j = 63 - __builtin_clzll(flags);
-    Splat nxt = load_splat<C>(rec, sorted_rank, start + (uint32_t)(cbase + j));
-    uint32_t inst_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorted_inst[start + (uint32_t)(cbase + j)]);
+    Splat nxt = load_splat_packed<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+    uint32_t inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
     while (true) {
       const Splat s = nxt;
       const uint32_t inst_j = inst_nxt;
@@ -248,8 +267,8 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
       const bool more = flags != 0ull;
       if (more) {                                             // prefetch the next contributing pair
         j = 63 - __builtin_clzll(flags);
-        nxt = load_splat<C>(rec, sorted_rank, start + (uint32_t)(cbase + j));
-        inst_nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorted_inst[start + (uint32_t)(cbase + j)]);
+        nxt = load_splat_packed<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+        inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
       }
       const float dxa = fx0 - s.u, dya = fy0 - s.v;
       const v2f dx2 = {dxa, dxa + 8.f};

@@ -63,3 +63,29 @@ def test_split_gaussians_uniform_matches_reference_rule():
   assert torch.allclose(mid, pts["position"], atol=1e-5)
   shrunk = out["log_scaling"][0::2].gather(1, axis[:, None]).squeeze(1)
   assert torch.allclose(shrunk, pts["log_scaling"].gather(1, axis[:, None]).squeeze(1) - 0.5 * torch.log(torch.tensor(2.0)))
+
+
+def test_config_c4_scaled_100_iterations():
+  """BASELINE config c4, scaled to fit a test: 200k Gaussians, 960x540, 4 cameras per step, 100 iterations,
+  densify/prune every 25 (TargetController maths, prune_rate 0.025, min_views 5, target +10 %).  The splat count
+  changes three times; every buffer of the path is re-sized per frame from M and O."""
+  import time
+  g, cams = synthetic.scene_b(200_000, 960, 540, sh_degree=1, seed=1, num_cameras=8, sigma_px=1.5)
+  dev = "cuda"
+  g = g.to(dev)
+  cams = [c.to(dev) for c in cams[:4]]
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  with torch.no_grad():
+    targets = [torch.full((540, 960, 3), 0.5, device=dev) for _ in cams]
+  tr = MiniTrainer(g, cams, targets, cfg, lr=1e-3, densify_every=25, target_points=220_000, prune_rate=0.025,
+                   min_views=5, total_steps=100, seed=0)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  log = tr.train(100)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  print(f"c4-scaled: {100 / dt:.1f} it/s, final N = {tr.num_points}, masks = {[d[:12] for d in log.mask_digests]}")
+  assert len(log.mask_digests) == 3 and len(set(log.mask_digests)) == 3     # three different split/prune rounds
+  assert log.num_points[0] == 200_000 and tr.num_points == 220_000          # reaches the controller's target
+  assert all(torch.isfinite(p).all() for p in tr.params.values())
+  assert log.losses[-1] < log.losses[0]

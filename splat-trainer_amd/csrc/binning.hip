@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict
   const uint32_t b = offsets[k], n = count[k];
   float acc = 0.f;
   for (uint32_t j = 0; j < n; ++j) acc += vis_partial[b + j];
-  vis[order[k]] = acc;
+  vis[order ? order[k] : (uint32_t)k] = acc;
 }
 
 // One block = 256 consecutive depth ranks = one CONTIGUOUS range of instance slots.  The range is streamed through
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
     __syncthreads();
   }
   if (!have) return;
-  const int64_t s = order[k];
+  const int64_t s = order ? (int64_t)order[k] : k;           // order == NULL: ranks are splat ids already
   float* g = dg2d + 6 * s;
   *reinterpret_cast<float2*>(g) = make_float2(a0.x, a0.y);
   *reinterpret_cast<float2*>(g + 2) = make_float2(a0.z, a0.w);
@@ -236,7 +236,7 @@ int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, con
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
-  if (!offsets || !count || !order || !visibility_out) return GSR_ERR_INVALID_ARGUMENT;
+  if (!offsets || !count || !visibility_out) return GSR_ERR_INVALID_ARGUMENT;
   reduce_vis_kernel<<<grid_for(M, 256), 256, 0, stream>>>(vis_partial, offsets, count, order, M, visibility_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
@@ -249,7 +249,7 @@ int gsr_reduce_gradients(const float* partial, const float* vis_partial, const u
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!offsets || !count || !order || !d_gaussians2d || !d_features || !prune_cost_out || !split_score_out)
+  if (!offsets || !count || !d_gaussians2d || !d_features || !prune_cost_out || !split_score_out)
     return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
   if (C == 1) reduce_grad_kernel<1><<<g, 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, d_gaussians2d, d_features, prune_cost_out, split_score_out);

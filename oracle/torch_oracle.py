@@ -280,7 +280,7 @@ def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None,
 
 def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image_size, config,
               dL_dimage: Optional[torch.Tensor] = None, want_median: bool = False,
-              tile_batch: int = 64, tiles: Optional[torch.Tensor] = None) -> RasterOutputs:
+              tile_batch: int = 64, tiles: Optional[torch.Tensor] = None, lists=None) -> RasterOutputs:
   """Tile-batched compositing of projected splats.  Differentiable wrt g2d and feats (autograd).
 
   ``dL_dimage`` (H,W,C): when given, also returns the per-point heuristics prune_cost / split_score
@@ -291,7 +291,8 @@ def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image
   M = g2d.shape[0]
   C = feats.shape[1]
   dtype, dev = g2d.dtype, g2d.device
-  splat_sorted, starts, counts, tw, th = _tile_lists(g2d, depth, image_size, config)
+  # ``lists``: the result of _tile_lists() when the caller renders several tile subsets of one frame
+  splat_sorted, starts, counts, tw, th = lists if lists is not None else _tile_lists(g2d, depth, image_size, config)
 
   image = torch.zeros(th * ts, tw * ts, C, dtype=dtype, device=dev)
   final_T = torch.ones(th * ts, tw * ts, dtype=dtype, device=dev)

@@ -55,7 +55,7 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 5) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 6) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -149,6 +149,23 @@ int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, con
 int gsr_reduce_gradients(const float* partial, const float* vis_partial, const uint32_t* offsets,
                          const uint32_t* count, const uint32_t* order, int64_t M, int32_t C, float* d_gaussians2d,
                          float* d_features, float* prune_cost_out, float* split_score_out, void* stream);
+
+/* ---- loss stage next to the path: fused SSIM, replaces the CUDA-only fused_ssim package
+ *      the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462; trainer/evaluation.py:7,42) ------------ */
+size_t gsr_ssim_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+/* Mean SSIM (11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2) of img1 vs img2, both
+ * [B,C,H,W] with arbitrary element strides (4 x int64 on the host: batch, channel, row, column -- NCHW,
+ * channels_last and (H,W,C) views all work).  crop = 0: mean over the whole map ("same"); crop = 5: mean over the map
+ * without its 5-pixel border ("valid", what the reference uses).  mean_out: device float.  dm_* ([B,C,H,W]
+ * contiguous, all three or none): derivative maps consumed by gsr_ssim_backward. */
+int gsr_ssim_forward(const float* img1, const float* img2, const int64_t* strides1_host, const int64_t* strides2_host,
+                     int32_t B, int32_t C, int32_t H, int32_t W, int32_t crop, float* mean_out, float* dm_dmu1,
+                     float* dm_dm11, float* dm_dm12, void* workspace, size_t workspace_bytes, void* stream);
+/* d_img1 (element strides strides_out_host) = grad_scale * d mean / d img1; grad_scale_dev: device float. */
+int gsr_ssim_backward(const float* img1, const float* img2, const int64_t* strides1_host, const int64_t* strides2_host,
+                      const int64_t* strides_out_host, int32_t B, int32_t C, int32_t H, int32_t W, const float* dm_dmu1,
+                      const float* dm_dm11, const float* dm_dm12, const float* grad_scale_dev, float* d_img1,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,225 @@
+// Fused SSIM forward / backward (the loss stage that produces dL/dimage for the composite backward).
+// Replaces the CUDA-only ``fused_ssim`` package the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462).
+//
+// One 16x16 output tile per 256-thread block and (batch, channel) plane.  The 26x26 input tile (5-pixel halo, zero
+// outside the image) is staged in LDS once; the separable 11-tap Gaussian is applied as a horizontal pass into LDS
+// (5 moment images x 26 rows x 16 columns) and a vertical pass in registers, so every input pixel is read from HBM
+// once per tile and all 5 (forward) / 3 (backward) convolutions share the staging.  HBM-bound stencil: forward reads
+// 2 and writes 3 planes, backward reads 5 and writes 1.
+// The mean is reduced without atomics: per-block partial sums in a fixed order, then one block adds them in order.
+#include "gsr_device.h"
+#include "../../include/gsplat_hip.h"
+
+namespace {
+
+constexpr int TS = 16;          // output tile side
+constexpr int HALO = 5;
+constexpr int IN = TS + 2 * HALO;   // 26
+
+struct Gauss11 {
+  float w[11];
+};
+
+// img element (b, c, y, x) at b*sB + c*sC + y*sH + x*sW (so NCHW, channels_last and (H,W,C) views all work)
+struct Strides {
+  int64_t sB, sC, sH, sW;
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+  v = gsr_wave_sum(v);                                   // fixed-order DPP tree
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_red[wave] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                       Strides st1, Strides st2, int C, int H, int W, int crop,
+                                                       float C1, float C2, float inv_count, Gauss11 g,
+                                                       float* __restrict__ block_sums, float* __restrict__ dm_dmu1,
+                                                       float* __restrict__ dm_dm11, float* __restrict__ dm_dm12) {
+  __shared__ float s_x[IN][IN + 1], s_y[IN][IN + 1];
+  __shared__ float s_h[5][IN][TS + 1];
+  __shared__ float s_red[4];
+  const int plane = blockIdx.z, b = plane / C, c = plane % C;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  const float* p1 = img1 + b * st1.sB + c * st1.sC;
+  const float* p2 = img2 + b * st2.sB + c * st2.sC;
+  for (int i = threadIdx.x; i < IN * IN; i += 256) {
+    const int ly = i / IN, lx = i % IN;
+    const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    s_x[ly][lx] = in ? p1[gy * st1.sH + gx * st1.sW] : 0.f;
+    s_y[ly][lx] = in ? p2[gy * st2.sH + gx * st2.sW] : 0.f;
+  }
+  __syncthreads();
+  // horizontal pass: 26 rows x 16 columns of the five moment images
+  for (int i = threadIdx.x; i < IN * TS; i += 256) {
+    const int ly = i / TS, lx = i % TS;
+    float a = 0.f, bb = 0.f, aa = 0.f, bb2 = 0.f, ab = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float x = s_x[ly][lx + k], y = s_y[ly][lx + k], w = g.w[k];
+      a += w * x; bb += w * y; aa += w * x * x; bb2 += w * y * y; ab += w * x * y;
+    }
+    s_h[0][ly][lx] = a; s_h[1][ly][lx] = bb; s_h[2][ly][lx] = aa; s_h[3][ly][lx] = bb2; s_h[4][ly][lx] = ab;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int gx = x0 + tx, gy = y0 + ty;
+  float mu1 = 0.f, mu2 = 0.f, m11 = 0.f, m22 = 0.f, m12 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = g.w[k];
+    mu1 += w * s_h[0][ty + k][tx]; mu2 += w * s_h[1][ty + k][tx];
+    m11 += w * s_h[2][ty + k][tx]; m22 += w * s_h[3][ty + k][tx]; m12 += w * s_h[4][ty + k][tx];
+  }
+  const bool inside = gx < W && gy < H;
+  const bool counted = inside && gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
+  const float s1 = m11 - mu1 * mu1, s2 = m22 - mu2 * mu2, s12 = m12 - mu1 * mu2;
+  const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2;
+  const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+  const float iB = 1.f / (B1 * B2);
+  const float ssim = A1 * A2 * iB;
+  const float total = block_sum_256(counted ? ssim : 0.f, s_red);
+  if (threadIdx.x == 0)
+    block_sums[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
+  if (TRAIN && inside) {
+    // derivatives of the map wrt mu1 and the raw moments m11 = G*x^2, m12 = G*xy; pre-scaled by 1/count and zero
+    // outside the averaged region, so the backward pass only has to convolve them
+    const float sc = counted ? inv_count : 0.f;
+    const float d_mu1 = 2.f * mu2 * (A2 - A1) * iB - 2.f * mu1 * A1 * A2 * (B2 - B1) * iB * iB;
+    const float d_m11 = -A1 * A2 * iB / B2;
+    const float d_m12 = 2.f * A1 * iB;
+    const int64_t o = ((int64_t)plane * H + gy) * W + gx;
+    dm_dmu1[o] = sc * d_mu1; dm_dm11[o] = sc * d_m11; dm_dm12[o] = sc * d_m12;
+  }
+}
+
+// one block adds the per-block partials in index order (fixed association) and scales by 1/count
+__global__ __launch_bounds__(256) void ssim_finish_kernel(const float* __restrict__ block_sums, int n, float inv_count,
+                                                          float* __restrict__ out) {
+  __shared__ float s_red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += block_sums[i];
+  const float total = block_sum_256(acc, s_red);
+  if (threadIdx.x == 0) out[0] = total * inv_count;
+}
+
+// dL/dimg1[p] = gscale * ( (G * d_mu1)[p] + 2 x[p] (G * d_m11)[p] + y[p] (G * d_m12)[p] )
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                       Strides st1, Strides st2, Strides sto, int C, int H, int W,
+                                                       Gauss11 g, const float* __restrict__ dm_dmu1,
+                                                       const float* __restrict__ dm_dm11,
+                                                       const float* __restrict__ dm_dm12,
+                                                       const float* __restrict__ gscale_dev, float* __restrict__ dimg1) {
+  __shared__ float s_in[3][IN][IN + 1];
+  __shared__ float s_h[3][IN][TS + 1];
+  const int plane = blockIdx.z, b = plane / C, c = plane % C;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  const int64_t pbase = (int64_t)plane * H * W;
+  for (int i = threadIdx.x; i < IN * IN; i += 256) {
+    const int ly = i / IN, lx = i % IN;
+    const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int64_t o = pbase + (int64_t)gy * W + gx;
+    s_in[0][ly][lx] = in ? dm_dmu1[o] : 0.f;
+    s_in[1][ly][lx] = in ? dm_dm11[o] : 0.f;
+    s_in[2][ly][lx] = in ? dm_dm12[o] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < IN * TS; i += 256) {
+    const int ly = i / TS, lx = i % TS;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = g.w[k];
+      a0 += w * s_in[0][ly][lx + k]; a1 += w * s_in[1][ly][lx + k]; a2 += w * s_in[2][ly][lx + k];
+    }
+    s_h[0][ly][lx] = a0; s_h[1][ly][lx] = a1; s_h[2][ly][lx] = a2;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int gx = x0 + tx, gy = y0 + ty;
+  if (gx >= W || gy >= H) return;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = g.w[k];
+    c0 += w * s_h[0][ty + k][tx]; c1 += w * s_h[1][ty + k][tx]; c2 += w * s_h[2][ty + k][tx];
+  }
+  const float x = img1[b * st1.sB + c * st1.sC + gy * st1.sH + gx * st1.sW];
+  const float y = img2[b * st2.sB + c * st2.sC + gy * st2.sH + gx * st2.sW];
+  dimg1[b * sto.sB + c * sto.sC + gy * sto.sH + gx * sto.sW] = gscale_dev[0] * (c0 + 2.f * x * c1 + y * c2);
+}
+
+Gauss11 make_gauss() {
+  Gauss11 g;
+  double sum = 0.0, w[11];
+  for (int i = 0; i < 11; ++i) { const double d = i - 5; w[i] = exp(-(d * d) / (2.0 * 1.5 * 1.5)); sum += w[i]; }
+  for (int i = 0; i < 11; ++i) g.w[i] = (float)(w[i] / sum);
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gsr_ssim_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 256;
+  const size_t blocks = (size_t)((W + TS - 1) / TS) * ((H + TS - 1) / TS) * B * C;
+  return blocks * sizeof(float) + 256;
+}
+
+// strides1/strides2/strides_out: 4 x int64 element strides (batch, channel, row, column).
+// crop = 0 ("same": mean over the whole map) or 5 ("valid").  mean_out: device float.  The three derivative maps
+// ([B,C,H,W] contiguous, may be NULL) are what gsr_ssim_backward consumes.
+int gsr_ssim_forward(const float* img1, const float* img2, const int64_t* strides1_host, const int64_t* strides2_host,
+                     int32_t B, int32_t C, int32_t H, int32_t W, int32_t crop, float* mean_out, float* dm_dmu1,
+                     float* dm_dm11, float* dm_dm12, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || crop < 0 || !img1 || !img2 || !mean_out || !strides1_host || !strides2_host)
+    return GSR_ERR_INVALID_ARGUMENT;
+  if (W - 2 * crop <= 0 || H - 2 * crop <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (!workspace || workspace_bytes < gsr_ssim_workspace_bytes(B, C, H, W)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  const bool train = dm_dmu1 && dm_dm11 && dm_dm12;
+  const Strides s1 = {strides1_host[0], strides1_host[1], strides1_host[2], strides1_host[3]};
+  const Strides s2 = {strides2_host[0], strides2_host[1], strides2_host[2], strides2_host[3]};
+  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
+  const int nblocks = grid.x * grid.y * grid.z;
+  const float inv_count = 1.f / ((float)B * C * (H - 2 * crop) * (float)(W - 2 * crop));
+  float* block_sums = reinterpret_cast<float*>(workspace);
+  const Gauss11 g = make_gauss();
+  if (train)
+    ssim_fwd_kernel<true><<<grid, 256, 0, stream>>>(img1, img2, s1, s2, C, H, W, crop, 0.01f * 0.01f, 0.03f * 0.03f,
+                                                   inv_count, g, block_sums, dm_dmu1, dm_dm11, dm_dm12);
+  else
+    ssim_fwd_kernel<false><<<grid, 256, 0, stream>>>(img1, img2, s1, s2, C, H, W, crop, 0.01f * 0.01f, 0.03f * 0.03f,
+                                                    inv_count, g, block_sums, nullptr, nullptr, nullptr);
+  GSR_CHECK_LAUNCH();
+  ssim_finish_kernel<<<1, 256, 0, stream>>>(block_sums, nblocks, inv_count, mean_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+// d_img1 = grad_scale * d mean_ssim / d img1;  grad_scale_dev: device float (the upstream gradient of the mean).
+int gsr_ssim_backward(const float* img1, const float* img2, const int64_t* strides1_host, const int64_t* strides2_host,
+                      const int64_t* strides_out_host, int32_t B, int32_t C, int32_t H, int32_t W, const float* dm_dmu1,
+                      const float* dm_dm11, const float* dm_dm12, const float* grad_scale_dev, float* d_img1,
+                      void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dm_dmu1 || !dm_dm11 || !dm_dm12 || !grad_scale_dev ||
+      !d_img1 || !strides1_host || !strides2_host || !strides_out_host)
+    return GSR_ERR_INVALID_ARGUMENT;
+  const Strides s1 = {strides1_host[0], strides1_host[1], strides1_host[2], strides1_host[3]};
+  const Strides s2 = {strides2_host[0], strides2_host[1], strides2_host[2], strides2_host[3]};
+  const Strides so = {strides_out_host[0], strides_out_host[1], strides_out_host[2], strides_out_host[3]};
+  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
+  ssim_bwd_kernel<<<grid, 256, 0, stream>>>(img1, img2, s1, s2, so, C, H, W, make_gauss(), dm_dmu1, dm_dm11, dm_dm12,
+                                           grad_scale_dev, d_img1);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+}  // extern "C"

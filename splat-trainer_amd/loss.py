@@ -1,0 +1,78 @@
+"""fused_ssim: the loss stage next to the rasterizer path.
+
+Same name and call shape as the CUDA-only ``fused_ssim`` package the reference imports
+(splat_trainer/trainer/trainer.py:17,112: ``partial(fused_ssim, padding="valid")``; trainer/evaluation.py:42), so
+``from splat_trainer_amd import fused_ssim`` is an import swap.  Mean SSIM with an 11x11 Gaussian window
+(sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2) of ``img1`` (the prediction, differentiable) against ``img2``,
+both (B, C, H, W) in any memory format -- the reference passes channels_last views of (H, W, 3) images
+(trainer.py:450-452); they are read through their strides, no copy is made.  HIP kernels behind the C ABI
+(csrc/ssim.hip); no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+  return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _strides(t: torch.Tensor):
+  return (C.c_int64 * 4)(*t.stride())
+
+
+class _SSIMFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, img1, img2, crop, train):
+    lib = _lib.load()
+    x = img1.detach().to(torch.float32)
+    y = img2.detach().to(torch.float32)
+    B, Cc, H, W = x.shape
+    dev = x.device
+    mean = torch.empty(1, dtype=torch.float32, device=dev)
+    maps = torch.empty(3, B, Cc, H, W, dtype=torch.float32, device=dev) if train else None
+    ws_bytes = lib.gsr_ssim_workspace_bytes(B, Cc, H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    m = (maps[0], maps[1], maps[2]) if train else (None, None, None)
+    _lib.check(lib.gsr_ssim_forward(_ptr(x), _ptr(y), _strides(x), _strides(y), B, Cc, H, W, crop, _ptr(mean),
+                                    _ptr(m[0]), _ptr(m[1]), _ptr(m[2]), _ptr(ws), ws_bytes, _stream()),
+               "gsr_ssim_forward")
+    ctx.save_for_backward(x, y, maps)
+    ctx.in_dtype = img1.dtype
+    return mean[0]
+
+  @staticmethod
+  def backward(ctx, g):
+    lib = _lib.load()
+    x, y, maps = ctx.saved_tensors
+    if maps is None:
+      raise _lib.GsplatHipError("fused_ssim(train=False) result cannot be back-propagated")
+    B, Cc, H, W = x.shape
+    gs = g.detach().to(torch.float32).reshape(1).contiguous()
+    d = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device)
+    _lib.check(lib.gsr_ssim_backward(_ptr(x), _ptr(y), _strides(x), _strides(y), _strides(d), B, Cc, H, W,
+                                     _ptr(maps[0]), _ptr(maps[1]), _ptr(maps[2]), _ptr(gs), _ptr(d), _stream()),
+               "gsr_ssim_backward")
+    return d.to(ctx.in_dtype), None, None, None
+
+
+def fused_ssim(img1: torch.Tensor, img2: torch.Tensor, padding: str = "same", train: bool = True) -> torch.Tensor:
+  if padding not in ("same", "valid"):
+    raise ValueError("padding must be 'same' or 'valid'")
+  if img1.dim() != 4 or img1.shape != img2.shape:
+    raise ValueError(f"expected two (B,C,H,W) tensors of equal shape, got {tuple(img1.shape)} and {tuple(img2.shape)}")
+  if not (img1.is_cuda and img2.is_cuda):
+    raise _lib.GsplatHipError("fused_ssim runs only on a HIP device; there is no CPU fallback")
+  crop = 5 if padding == "valid" else 0
+  if img1.shape[2] <= 2 * crop or img1.shape[3] <= 2 * crop:
+    raise ValueError("image too small for padding='valid' (needs more than 10 pixels per side)")
+  train = bool(train and torch.is_grad_enabled() and img1.requires_grad)
+  return _SSIMFn.apply(img1, img2, crop, train)

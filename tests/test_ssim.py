@@ -1,0 +1,116 @@
+"""Fused SSIM.  CPU: the oracle against a direct definition-level evaluation and known
+properties.  GPU: the HIP kernels through the C ABI against the oracle (fp64) -- value and gradient, both paddings,
+planar and channels_last inputs, odd sizes -- and the reference's multi-scale loss (trainer.py:450-462)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ssim_oracle
+
+
+def _naive_ssim_at(x, y, py, px):
+  """SSIM of one pixel straight from the definition (zero padding), pure Python loops."""
+  H, W = x.shape
+  g = ssim_oracle.gaussian_window(torch.float64)
+  m1 = m2 = m11 = m22 = m12 = 0.0
+  for dy in range(-5, 6):
+    for dx in range(-5, 6):
+      yy, xx = py + dy, px + dx
+      if 0 <= yy < H and 0 <= xx < W:
+        w = (g[dy + 5] * g[dx + 5]).item()
+        a, b = x[yy, xx].item(), y[yy, xx].item()
+        m1 += w * a; m2 += w * b; m11 += w * a * a; m22 += w * b * b; m12 += w * a * b
+  s1, s2, s12 = m11 - m1 * m1, m22 - m2 * m2, m12 - m1 * m2
+  return ((2 * m1 * m2 + ssim_oracle.C1) * (2 * s12 + ssim_oracle.C2)) / ((m1 * m1 + m2 * m2 + ssim_oracle.C1) * (s1 + s2 + ssim_oracle.C2))
+
+
+def test_oracle_matches_definition_and_properties():
+  torch.manual_seed(0)
+  x = torch.rand(1, 2, 19, 23, dtype=torch.float64)
+  y = (x + 0.2 * torch.randn_like(x)).clamp(0, 1)
+  m = ssim_oracle.ssim_map(x, y)
+  for (py, px) in [(0, 0), (9, 11), (18, 22), (5, 3), (13, 20)]:
+    assert abs(m[0, 1, py, px].item() - _naive_ssim_at(x[0, 1], y[0, 1], py, px)) < 1e-12
+  assert abs(ssim_oracle.fused_ssim(x, x, "valid").item() - 1.0) < 1e-12          # identical images
+  assert ssim_oracle.fused_ssim(x, y, "valid").item() < 1.0
+  assert abs(ssim_oracle.fused_ssim(x, y, "same").item() - ssim_oracle.fused_ssim(y, x, "same").item()) < 1e-12
+  g = ssim_oracle.gaussian_window()
+  assert abs(g.sum().item() - 1) < 1e-15 and g.argmax().item() == 5
+  xg = x.clone().requires_grad_(True)
+  assert torch.autograd.gradcheck(lambda t: ssim_oracle.fused_ssim(t, y, "valid"), (xg,), eps=1e-6, atol=1e-7)
+
+
+def test_fused_ssim_refuses_cpu():
+  import splat_trainer_amd as sta
+  with pytest.raises(sta.GsplatHipError):
+    sta.fused_ssim(torch.rand(1, 3, 32, 32), torch.rand(1, 3, 32, 32))
+  with pytest.raises(ValueError):
+    sta.fused_ssim(torch.rand(1, 3, 32, 32).to("meta") if False else torch.rand(3, 32, 32), torch.rand(3, 32, 32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,padding,layout", [((1, 3, 64, 80), "valid", "nchw"), ((2, 1, 33, 47), "same", "nchw"),
+                                                  ((1, 3, 100, 37), "valid", "hwc"), ((1, 3, 16, 16), "same", "hwc"),
+                                                  ((1, 3, 12, 200), "valid", "nchw")])
+def test_hip_ssim_matches_oracle(shape, padding, layout):
+  import splat_trainer_amd as sta
+  torch.manual_seed(sum(shape))
+  B, C, H, W = shape
+  x = torch.rand(B, C, H, W)
+  y = (x + 0.15 * torch.randn(B, C, H, W)).clamp(0, 1)
+  if layout == "hwc":      # the reference's channels_last view of an (H, W, C) image (trainer.py:450-452)
+    xd = x[0].permute(1, 2, 0).contiguous().cuda().requires_grad_(True)
+    yd = y[0].permute(1, 2, 0).contiguous().cuda()
+    a, b = xd.unsqueeze(0).permute(0, 3, 1, 2), yd.unsqueeze(0).permute(0, 3, 1, 2)
+    assert not a.is_contiguous()
+  else:
+    xd = x.clone().cuda().requires_grad_(True)
+    yd = y.cuda()
+    a, b = xd, yd
+  got = sta.fused_ssim(a, b, padding=padding)
+  xo = x.double().requires_grad_(True)
+  want = ssim_oracle.fused_ssim(xo, y.double(), padding)
+  assert got.dim() == 0 and abs(got.item() - want.item()) < 2e-6
+  (got * 3.0).backward()
+  (want * 3.0).backward()
+  gd = xd.grad if layout != "hwc" else xd.grad.permute(2, 0, 1).unsqueeze(0)
+  err = (gd.cpu().double() - xo.grad).abs().max().item() / xo.grad.abs().max().item()
+  assert err < 1e-4, err
+  # deterministic (no atomics) and usable without grad
+  again = sta.fused_ssim(a.detach(), b, padding=padding, train=False)
+  assert again.item() == got.item()
+
+
+@pytest.mark.gpu
+def test_reference_multiscale_loss_flow():
+  """trainer.py:450-462 with the import swapped: 3 levels, 2x average pooling, padding='valid', HWC image."""
+  import splat_trainer_amd as sta
+  from functools import partial
+  torch.manual_seed(5)
+  H, W = 270, 480
+  ref = torch.rand(H, W, 3)
+  pred = (ref + 0.1 * torch.randn(H, W, 3)).clamp(0, 1)
+  ssim_hip = partial(sta.fused_ssim, padding="valid")                      # trainer.py:112
+
+  def compute_ssim_loss(pred, ref, levels, ssim):                          # trainer.py:450-462, verbatim structure
+    ref = ref.unsqueeze(0).permute(0, 3, 1, 2).to(memory_format=torch.channels_last)
+    pred = pred.unsqueeze(0).permute(0, 3, 1, 2).to(memory_format=torch.channels_last)
+    s = ssim(pred, ref)
+    loss = 1.0 - s
+    for _ in range(1, levels):
+      pred = F.avg_pool2d(pred, kernel_size=2, stride=2)
+      ref = F.avg_pool2d(ref, kernel_size=2, stride=2)
+      loss = loss + (1.0 - ssim(pred, ref))
+    return loss / levels, s.item()
+
+  pd = pred.clone().cuda().requires_grad_(True)
+  loss, s0 = compute_ssim_loss(pd, ref.cuda(), 3, ssim_hip)
+  loss.backward()
+  po = pred.clone().double().requires_grad_(True)
+  oloss, os0 = ssim_oracle.multiscale_ssim_loss(po, ref.double(), levels=3)
+  oloss.backward()
+  assert abs(loss.item() - oloss.item()) < 2e-6 and abs(s0 - os0.item()) < 2e-6
+  err = (pd.grad.cpu().double() - po.grad).abs().max().item() / po.grad.abs().max().item()
+  assert err < 1e-4, err

@@ -1,20 +1,20 @@
 // Fused SSIM forward / backward (the loss stage that produces dL/dimage for the composite backward).
 // Replaces the CUDA-only ``fused_ssim`` package the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462).
 //
-// One 16x16 output tile per 256-thread block and (batch, channel) plane.  The 26x26 input tile (5-pixel halo, zero
+// One 32x32 output tile per 256-thread block and (batch, channel) plane.  The 42x42 input tile (5-pixel halo, zero
 // outside the image) is staged in LDS once; the separable 11-tap Gaussian is applied as a horizontal pass into LDS
-// (5 moment images x 26 rows x 16 columns) and a vertical pass in registers, so every input pixel is read from HBM
-// once per tile and all 5 (forward) / 3 (backward) convolutions share the staging.  HBM-bound stencil: forward reads
-// 2 and writes 3 planes, backward reads 5 and writes 1.
+// (5 moment images x 42 rows x 32 columns) and a vertical pass in registers, 4 outputs per work item, so every input
+// pixel is read from HBM once per tile and all 5 (forward) / 3 (backward) convolutions share the staging.
+// Forward reads 2 and writes 3 planes, backward reads 5 and writes 1.
 // The mean is reduced without atomics: per-block partial sums in a fixed order, then one block adds them in order.
 #include "gsr_device.h"
 #include "../../include/gsplat_hip.h"
 
 namespace {
 
-constexpr int TS = 16;          // output tile side
+constexpr int TS = 32;              // output tile side (256 threads: 8 column groups / row groups of 4)
 constexpr int HALO = 5;
-constexpr int IN = TS + 2 * HALO;   // 26
+constexpr int IN = TS + 2 * HALO;   // 42
 
 struct Gauss11 {
   float w[11];
@@ -33,6 +33,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
   return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+// Register blocking: a work item produces 4 adjacent outputs from 14 staged inputs, so an 11-tap pass costs 3.5 LDS
+// reads per output and image instead of 11 (the first version of this kernel was LDS-read bound at ~90 reads/pixel).
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
                                                        Strides st1, Strides st2, int C, int H, int W, int crop,
@@ -54,47 +56,72 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
     s_y[ly][lx] = in ? p2[gy * st2.sH + gx * st2.sW] : 0.f;
   }
   __syncthreads();
-  // horizontal pass: 26 rows x 16 columns of the five moment images
-  for (int i = threadIdx.x; i < IN * TS; i += 256) {
-    const int ly = i / TS, lx = i % TS;
-    float a = 0.f, bb = 0.f, aa = 0.f, bb2 = 0.f, ab = 0.f;
+  // horizontal pass: 42 rows x 8 groups of 4 columns
+  for (int i = threadIdx.x; i < IN * (TS / 4); i += 256) {
+    const int ly = i / (TS / 4), lx = (i % (TS / 4)) * 4;
+    float x[14], y[14], xx[14], yy[14], xy[14];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float x = s_x[ly][lx + k], y = s_y[ly][lx + k], w = g.w[k];
-      a += w * x; bb += w * y; aa += w * x * x; bb2 += w * y * y; ab += w * x * y;
+    for (int k = 0; k < 14; ++k) {
+      x[k] = s_x[ly][lx + k]; y[k] = s_y[ly][lx + k];
+      xx[k] = x[k] * x[k]; yy[k] = y[k] * y[k]; xy[k] = x[k] * y[k];
     }
-    s_h[0][ly][lx] = a; s_h[1][ly][lx] = bb; s_h[2][ly][lx] = aa; s_h[3][ly][lx] = bb2; s_h[4][ly][lx] = ab;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float a = 0.f, bb = 0.f, aa = 0.f, bb2 = 0.f, ab = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float w = g.w[k];
+        a += w * x[o + k]; bb += w * y[o + k]; aa += w * xx[o + k]; bb2 += w * yy[o + k]; ab += w * xy[o + k];
+      }
+      s_h[0][ly][lx + o] = a; s_h[1][ly][lx + o] = bb; s_h[2][ly][lx + o] = aa; s_h[3][ly][lx + o] = bb2;
+      s_h[4][ly][lx + o] = ab;
+    }
   }
   __syncthreads();
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int gx = x0 + tx, gy = y0 + ty;
-  float mu1 = 0.f, mu2 = 0.f, m11 = 0.f, m22 = 0.f, m12 = 0.f;
+  // vertical pass: thread = (column, group of 4 rows)
+  const int tx = threadIdx.x & 31, tg = threadIdx.x >> 5;
+  const int gx = x0 + tx;
+  float acc[4][5];
 #pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float w = g.w[k];
-    mu1 += w * s_h[0][ty + k][tx]; mu2 += w * s_h[1][ty + k][tx];
-    m11 += w * s_h[2][ty + k][tx]; m22 += w * s_h[3][ty + k][tx]; m12 += w * s_h[4][ty + k][tx];
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[o][q] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    float col[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) col[k] = s_h[q][tg * 4 + k][tx];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int k = 0; k < 11; ++k) acc[o][q] += g.w[k] * col[o + k];
   }
-  const bool inside = gx < W && gy < H;
-  const bool counted = inside && gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
-  const float s1 = m11 - mu1 * mu1, s2 = m22 - mu2 * mu2, s12 = m12 - mu1 * mu2;
-  const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2;
-  const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
-  const float iB = 1.f / (B1 * B2);
-  const float ssim = A1 * A2 * iB;
-  const float total = block_sum_256(counted ? ssim : 0.f, s_red);
+  float local = 0.f;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int gy = y0 + tg * 4 + o;
+    const float mu1 = acc[o][0], mu2 = acc[o][1], m11 = acc[o][2], m22 = acc[o][3], m12 = acc[o][4];
+    const bool inside = gx < W && gy < H;
+    const bool counted = inside && gx >= crop && gx < W - crop && gy >= crop && gy < H - crop;
+    const float s1 = m11 - mu1 * mu1, s2 = m22 - mu2 * mu2, s12 = m12 - mu1 * mu2;
+    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2;
+    const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+    const float iB = 1.f / (B1 * B2);
+    if (counted) local += A1 * A2 * iB;
+    if (TRAIN && inside) {
+      // derivatives of the map wrt mu1 and the raw moments m11 = G*x^2, m12 = G*xy; pre-scaled by 1/count and zero
+      // outside the averaged region, so the backward pass only has to convolve them
+      const float sc = counted ? inv_count : 0.f;
+      const float d_mu1 = 2.f * mu2 * (A2 - A1) * iB - 2.f * mu1 * A1 * A2 * (B2 - B1) * iB * iB;
+      const float d_m11 = -A1 * A2 * iB / B2;
+      const float d_m12 = 2.f * A1 * iB;
+      const int64_t oidx = ((int64_t)plane * H + gy) * W + gx;
+      dm_dmu1[oidx] = sc * d_mu1; dm_dm11[oidx] = sc * d_m11; dm_dm12[oidx] = sc * d_m12;
+    }
+  }
+  const float total = block_sum_256(local, s_red);
   if (threadIdx.x == 0)
     block_sums[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
-  if (TRAIN && inside) {
-    // derivatives of the map wrt mu1 and the raw moments m11 = G*x^2, m12 = G*xy; pre-scaled by 1/count and zero
-    // outside the averaged region, so the backward pass only has to convolve them
-    const float sc = counted ? inv_count : 0.f;
-    const float d_mu1 = 2.f * mu2 * (A2 - A1) * iB - 2.f * mu1 * A1 * A2 * (B2 - B1) * iB * iB;
-    const float d_m11 = -A1 * A2 * iB / B2;
-    const float d_m12 = 2.f * A1 * iB;
-    const int64_t o = ((int64_t)plane * H + gy) * W + gx;
-    dm_dmu1[o] = sc * d_mu1; dm_dm11[o] = sc * d_m11; dm_dm12[o] = sc * d_m12;
-  }
 }
 
 // one block adds the per-block partials in index order (fixed association) and scales by 1/count
@@ -129,29 +156,49 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     s_in[2][ly][lx] = in ? dm_dm12[o] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < IN * TS; i += 256) {
-    const int ly = i / TS, lx = i % TS;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int i = threadIdx.x; i < IN * (TS / 4); i += 256) {
+    const int ly = i / (TS / 4), lx = (i % (TS / 4)) * 4;
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = g.w[k];
-      a0 += w * s_in[0][ly][lx + k]; a1 += w * s_in[1][ly][lx + k]; a2 += w * s_in[2][ly][lx + k];
+    for (int q = 0; q < 3; ++q) {
+      float v[14];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) v[k] = s_in[q][ly][lx + k];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a += g.w[k] * v[o + k];
+        s_h[q][ly][lx + o] = a;
+      }
     }
-    s_h[0][ly][lx] = a0; s_h[1][ly][lx] = a1; s_h[2][ly][lx] = a2;
   }
   __syncthreads();
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int gx = x0 + tx, gy = y0 + ty;
-  if (gx >= W || gy >= H) return;
-  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  const int tx = threadIdx.x & 31, tg = threadIdx.x >> 5;
+  const int gx = x0 + tx;
+  float acc[4][3];
 #pragma unroll
-  for (int k = 0; k < 11; ++k) {
-    const float w = g.w[k];
-    c0 += w * s_h[0][ty + k][tx]; c1 += w * s_h[1][ty + k][tx]; c2 += w * s_h[2][ty + k][tx];
+  for (int q = 0; q < 3; ++q) {
+    float col[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) col[k] = s_h[q][tg * 4 + k][tx];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) a += g.w[k] * col[o + k];
+      acc[o][q] = a;
+    }
   }
-  const float x = img1[b * st1.sB + c * st1.sC + gy * st1.sH + gx * st1.sW];
-  const float y = img2[b * st2.sB + c * st2.sC + gy * st2.sH + gx * st2.sW];
-  dimg1[b * sto.sB + c * sto.sC + gy * sto.sH + gx * sto.sW] = gscale_dev[0] * (c0 + 2.f * x * c1 + y * c2);
+  if (gx >= W) return;
+  const float gs = gscale_dev[0];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int gy = y0 + tg * 4 + o;
+    if (gy >= H) continue;
+    const float x = img1[b * st1.sB + c * st1.sC + gy * st1.sH + gx * st1.sW];
+    const float y = img2[b * st2.sB + c * st2.sC + gy * st2.sH + gx * st2.sW];
+    dimg1[b * sto.sB + c * sto.sC + gy * sto.sH + gx * sto.sW] = gs * (acc[o][0] + 2.f * x * acc[o][1] + y * acc[o][2]);
+  }
 }
 
 Gauss11 make_gauss() {

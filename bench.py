@@ -119,14 +119,21 @@ def main():
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--collective", default="all_reduce", choices=["reduce_scatter", "all_reduce"],
-                  help="one fused all_reduce of the flat gradient buffer (default: RCCL spreads it over all xGMI links "
-                       "with several channels), or reduce_scatter + all_gather of the same buffer")
+  ap.add_argument("--collective", default="auto", choices=["auto", "reduce_scatter", "all_reduce", "sh_factor"],
+                  help="auto (default) = sh_factor when WORLD_SIZE > 1, plain fused accumulation on one GPU; one fused all_reduce of the flat gradient buffer (default: RCCL spreads it over all xGMI links "
+                       "with several channels); reduce_scatter + all_gather of the same buffer; or sh_factor: all_reduce "
+                       "only the geometry gradients and all_gather the per-camera colour gradients (3 floats/splat), "
+                       "rebuilding the SH coefficient gradient (48 floats/splat) on every rank")
+  ap.add_argument("--check-collective", action="store_true",
+                  help="after the timed run, do one step with all_reduce and one with --collective and report the "
+                       "largest relative difference of the summed gradients (rehearsal aid; not timed)")
   ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                   help="nccl = RCCL over xGMI (default); gloo only for rehearsing the multi-rank path on one GPU")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
+  if args.collective == "auto":
+    args.collective = "sh_factor" if world > 1 else "all_reduce"
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if world != args.gpus and world > 1:
@@ -153,7 +160,12 @@ def main():
   N = g.position.shape[0]
   params = [t.to(dev).requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
   position, log_scaling, rotation, alpha_logit, feature = params
-  bucket = GradBucket(params, world, extra=N)              # + the per-point `visible` accumulator (mlp_scene.py:244)
+  from splat_trainer_amd.distributed import exchange_sh_factors
+  factor_mode = args.collective == "sh_factor"
+  # + the per-point `visible` accumulator (mlp_scene.py:244)
+  bucket = GradBucket(params[:4] if factor_mode else params, world, extra=N)
+  feature_grad = torch.zeros_like(feature) if factor_mode else None
+  collector = sta.ShFactorCollector() if factor_mode else None
   my_cams = [cams[j].to(dev) for j in shard_cameras(world, rank, world)]   # one camera per rank per step
   target_image = torch.full((w["h"], w["w"], 3), 0.5, device=dev)
   scene = sta.Gaussians3D(position=position, rotation=rotation, log_scaling=log_scaling, alpha_logit=alpha_logit,
@@ -161,19 +173,25 @@ def main():
   # gradients accumulate straight into the flat collective buffer (the reference accumulates into .grad over
   # the cameras of a batch, trainer.py:500-514)
   grad_out = sta.GradOut(position=bucket.views[0], log_scaling=bucket.views[1], rotation=bucket.views[2],
-                         alpha_logit=bucket.views[3], feature=bucket.views[4])
+                         alpha_logit=bucket.views[3], feature=None if factor_mode else bucket.views[4])
   last = {}
 
   def step():
     bucket.zero()
     for cam in my_cams:
       with torch.enable_grad():
-        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out)
+        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
         loss = torch.nn.functional.mse_loss(r.image.clamp(0, 1), target_image)    # trainer.py:472-475
         loss.backward()
       bucket.extra.index_add_(0, r.points.idx, r.points.visibility)
       last["r"] = r
-    bucket.all_reduce(mode=args.collective)
+    if factor_mode:
+      bucket.all_reduce(mode="all_reduce")                   # geometry gradients + visible accumulator (11+1 floats/splat)
+      feature_grad.zero_()
+      exchange_sh_factors(collector, list(range(len(my_cams))), len(my_cams), feature, position, feature_grad,
+                          bucket.views[0])                   # after the reduce: adds the term of ALL cameras
+    else:
+      bucket.all_reduce(mode=args.collective)
 
   def sync():
     torch.cuda.synchronize()
@@ -196,6 +214,20 @@ def main():
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+  check = None
+  if args.check_collective and factor_mode:
+    step()
+    got = [v.clone() for v in bucket.views[:4]] + [feature_grad.clone()]
+    ref_bucket = GradBucket(params, world, extra=N)
+    ref_out = sta.GradOut(*ref_bucket.views[:5])
+    for cam in my_cams:
+      with torch.enable_grad():
+        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=ref_out)
+        torch.nn.functional.mse_loss(r.image.clamp(0, 1), target_image).backward()
+    ref_bucket.all_reduce(mode="all_reduce")
+    check = max(float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(got, ref_bucket.views[:5]))
+    bucket.attach()
 
   r = last["r"]
   M, O = int(r.points.idx.shape[0]), int(r.num_overlaps)
@@ -225,7 +257,9 @@ def main():
         "config": {"workload": f"{args.workload}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, "
                                f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on",
                    "gaussians": N, "visible": M, "tile_overlaps": O, "pixels": P, "cameras_per_step": cameras_per_step,
-                   "parallelism": f"dp{world} (camera-sharded, fused {args.collective} of {bucket.flat.numel() * 4 / 1e6:.0f} MB grads)",
+                   "parallelism": (f"dp{world} (camera-sharded, all_reduce of {bucket.flat.numel() * 4 / 1e6:.0f} MB geometry "
+                                   f"grads + all_gather of {world * N * 12 / 1e6:.0f} MB colour-gradient factors)" if factor_mode else
+                                   f"dp{world} (camera-sharded, fused {args.collective} of {bucket.flat.numel() * 4 / 1e6:.0f} MB grads)"),
                    "psnr_note": "parity vs CPU oracle is asserted by tests/test_gpu_render.py (PSNR > 100 dB on c1)"},
         "roofline": {"bound": "hbm", "kernel": "composite_bwd_kernel<3> (K7 alpha-composite backward)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -234,6 +268,8 @@ def main():
                      "avg_launch_ms": ms_bwd, "launches_timed": n_bwd,
                      "composite_forward_avg_ms": ms_fwd},
     }
+    if check is not None:
+      out["config"]["collective_check_rel_err"] = check
     if world == 1 and not args.no_cpu_baseline:
       try:
         out["cpu_baseline"] = cpu_baseline(g, cams[0], cfg)

@@ -6,10 +6,10 @@ whose name carries a hyphen)."""
 from .data_types import (CameraParams, Gaussians3D, RasterConfig, RenderedPoints, Rendering,
                          pop_raster_config)
 from .renderer import GradOut, frustum_cull, project_to_image, render_gaussians, render_projected
-from .sh import evaluate_sh_at
+from .sh import ShFactorCollector, evaluate_sh_at
 from .loss import fused_ssim
 from ._lib import GsplatHipError
 
 __all__ = ["CameraParams", "Gaussians3D", "RasterConfig", "RenderedPoints", "Rendering", "pop_raster_config",
            "frustum_cull", "project_to_image", "render_projected", "render_gaussians", "evaluate_sh_at",
-           "GsplatHipError", "GradOut", "fused_ssim"]
+           "GsplatHipError", "GradOut", "fused_ssim", "ShFactorCollector"]

@@ -227,6 +227,66 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// Multi-camera SH backward for the data-parallel path: instead of all-reducing the (N,3,K) coefficient gradient (81 %
+// of the gradient bytes at K = 16), ranks all-gather the (cameras,N,3) colour gradients -- 16x smaller -- and every
+// rank rebuilds  d_sh[i] = sum_c g_c[i] (x) Y(dir_c(i))  locally, cameras in index order (deterministic and identical
+// on every rank, unlike the association order of a ring all-reduce).  Positions and coefficients are replicated, so
+// the basis and the view-direction Jacobian are recomputed from them.  Rows with an all-zero colour gradient (splat
+// not seen by that camera) are skipped.
+template <int K>
+__global__ __launch_bounds__(256) void sh_bwd_multi_kernel(const float* __restrict__ G, const float* __restrict__ cams,
+                                                           int ncam, const float* __restrict__ sh,
+                                                           const float* __restrict__ pos, int64_t N,
+                                                           float* __restrict__ dsh, float* __restrict__ dpos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+  const float* coef = sh + (int64_t)3 * K * i;
+  float acc[3][K];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[ch][k] = 0.f;
+  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+  bool any = false;
+  for (int c = 0; c < ncam; ++c) {
+    const float* g = G + ((int64_t)c * N + i) * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
+    any = true;
+    const float vx = px - cams[3 * c], vy = py - cams[3 * c + 1], vz = pz - cams[3 * c + 2];
+    const float inv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
+    const float x = vx * inv, y = vy * inv, z = vz * inv;
+    float Y[K];
+    gsr_sh_basis<K>(x, y, z, Y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      acc[0][k] += g0 * Y[k]; acc[1][k] += g1 * Y[k]; acc[2][k] += g2 * Y[k];
+    }
+    if (dpos != nullptr && K > 1) {
+      float dYx[K], dYy[K], dYz[K];
+      gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+      for (int k = 1; k < K; ++k) {
+        const float w = g0 * coef[k] + g1 * coef[K + k] + g2 * coef[2 * K + k];
+        gx += w * dYx[k]; gy += w * dYy[k]; gz += w * dYz[k];
+      }
+      const float dot = gx * x + gy * y + gz * z;
+      gpx += (gx - x * dot) * inv; gpy += (gy - y * dot) * inv; gpz += (gz - z * dot) * inv;
+    }
+  }
+  if (!any) return;
+  float* row = dsh + (int64_t)3 * K * i;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int k = 0; k < K; ++k) row[ch * K + k] += acc[ch][k];
+  if (dpos != nullptr && K > 1) {
+    dpos[3 * i] += gpx; dpos[3 * i + 1] += gpy; dpos[3 * i + 2] += gpz;
+  }
+}
+
 inline GsrRasterParams to_params(const GsrRasterParamsC* c) {
   GsrRasterParams rp;
   __builtin_memcpy(&rp, c, sizeof(rp));
@@ -239,7 +299,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 6; }
+int gsr_abi_version(void) { return 7; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -382,6 +442,25 @@ int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const flo
       if (accumulate) sh_bwd_kernel<16, true><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
       else sh_bwd_kernel<16, false><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, indexes, M, camera_pos, d_sh_features, d_positions, jacobian);
       break;
+  }
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_sh_backward_multi(const float* dL_dcolors_dense, const float* camera_positions, int32_t num_cameras,
+                          const float* sh_features, const float* positions, int64_t N, int32_t K, float* d_sh_features,
+                          float* d_positions, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || num_cameras < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
+  if (N == 0 || num_cameras == 0) return GSR_OK;
+  if (!dL_dcolors_dense || !camera_positions || !sh_features || !positions || !d_sh_features) return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(N, 256);
+  switch (K) {
+    case 1: sh_bwd_multi_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
+    case 4: sh_bwd_multi_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
+    case 9: sh_bwd_multi_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
+    default: sh_bwd_multi_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
   }
   GSR_CHECK_LAUNCH();
   return GSR_OK;

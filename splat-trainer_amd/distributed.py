@@ -70,6 +70,45 @@ class GradBucket:
       dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
 
+def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, sh_features: torch.Tensor,
+                        positions: torch.Tensor, d_sh: torch.Tensor, d_pos: Optional[torch.Tensor], group=None):
+  """All-gathers the colour-gradient factors recorded by a ``ShFactorCollector`` and adds the summed SH coefficient
+  gradient of ALL cameras of the batch to ``d_sh`` (N,3,K) -- and the view-direction term to ``d_pos`` (N,3) -- on every
+  rank.  ``d_sh`` / ``d_pos`` therefore must NOT be all-reduced afterwards.
+
+  Why: at K = 16 the coefficient gradient is 48 of the 59 floats per splat that a gradient all-reduce moves; its
+  per-camera factors (3 floats per splat + 3 per camera) are 16x smaller, positions and coefficients are replicated,
+  and xGMI traffic, not the rebuild (one pass over the rows), is what bounds data-parallel scaling here.  The sum runs
+  over cameras in slot order on every rank: deterministic and identical everywhere.
+
+  ``camera_slots[i]``: slot (0..cameras_per_rank-1) of the i-th recorded camera on this rank; every rank contributes
+  exactly ``cameras_per_rank`` slots (unused ones stay zero), so the gather is one fixed-size collective."""
+  import ctypes as C
+  from . import _lib
+  lib = _lib.load()
+  N, _, K = sh_features.shape
+  dev = sh_features.device
+  G = torch.zeros(cameras_per_rank, N, 3, dtype=torch.float32, device=dev)
+  cams = torch.zeros(cameras_per_rank, 3, dtype=torch.float32, device=dev)
+  assert len(collector.items) == len(camera_slots)
+  for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
+    G[slot].index_copy_(0, idx, dcol)
+    cams[slot].copy_(cam)
+  ws = dist.get_world_size(group) if dist.is_initialized() else 1
+  if ws > 1:
+    G_all = torch.empty(ws * cameras_per_rank, N, 3, dtype=torch.float32, device=dev)
+    cams_all = torch.empty(ws * cameras_per_rank, 3, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(G_all, G, group=group)
+    dist.all_gather_into_tensor(cams_all, cams, group=group)
+  else:
+    G_all, cams_all = G, cams
+  ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+  _lib.check(lib.gsr_sh_backward_multi(ptr(G_all), ptr(cams_all), G_all.shape[0], ptr(sh_features.detach()),
+                                       ptr(positions.detach()), N, K, ptr(d_sh), ptr(d_pos),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_sh_backward_multi")
+  collector.clear()
+
+
 def gather_point_stats(local: List[dict], num_cameras: int, group=None) -> List[dict]:
   """All-gathers the per-camera point statistics (idx, screen_scale_max, visibility, split_score,
   prune_cost) and returns them for ALL cameras in camera order, identical on every rank.

@@ -376,7 +376,7 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
 
 def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config: Optional[RasterConfig] = None,
                      use_sh: bool = False, render_median_depth: bool = False, grad_out: Optional[GradOut] = None,
-                     **options) -> Rendering:
+                     sh_collector=None, **options) -> Rendering:
   """One-call form (splat_trainer/scripts/test_split.py:30): project -> colour -> rasterize.
   ``use_sh``: ``gaussians.feature`` is (N, 3, K) SH coefficients evaluated towards the camera;
   otherwise it is an (N, C) per-point colour."""
@@ -384,7 +384,9 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
   g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out)
   if use_sh:
     sh_out = None
-    if grad_out is not None:
+    if sh_collector is not None:            # data-parallel: exchange colour-gradient factors, not d_sh (sh.py)
+      sh_out = sh_collector
+    elif grad_out is not None:
       sh_out = (grad_out._check("feature", gaussians.feature), grad_out._check("position", gaussians.position))
     feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_params.camera_position,
                            grad_out=sh_out)

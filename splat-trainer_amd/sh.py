@@ -22,6 +22,19 @@ def _stream():
   return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class ShFactorCollector:
+  """Data-parallel helper: instead of forming the (N,3,K) coefficient gradient per camera, the backward pass of
+  ``evaluate_sh_at`` only records the per-camera colour gradient (M,3) here; ``distributed.exchange_sh_factors``
+  later all-gathers the 16x smaller factors over the ranks and one fused kernel rebuilds the summed coefficient
+  gradient on every rank (csrc/geometry.hip: sh_bwd_multi_kernel)."""
+
+  def __init__(self):
+    self.items = []            # (indexes (M,), d_colour (M,3), camera_pos (3,)) in the order backward ran
+
+  def clear(self):
+    self.items.clear()
+
+
 class _SHFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad):
@@ -50,6 +63,9 @@ class _SHFn(torch.autograd.Function):
     N, _, K = sh.shape
     M = idx.shape[0]
     go = ctx.grad_out
+    if isinstance(go, ShFactorCollector):    # data-parallel factor exchange: keep only the colour gradient
+      go.items.append((idx, d_out.detach().to(torch.float32).contiguous(), cam))
+      return None, None, None, None, None, None
     if go is not None:                       # fused "+=" into caller-owned buffers (see renderer.GradOut)
       d_sh, d_pos = go
     else:
@@ -82,5 +98,6 @@ def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: 
     raise ValueError(f"sh_features must be (N,3,K) with K in (1,4,9,16), got {tuple(sh_features.shape)}")
   if indexes.dtype != torch.int64:
     raise TypeError("indexes must be int64")
-  want_pos_grad = torch.is_grad_enabled() and (positions.requires_grad or (grad_out is not None and grad_out[1] is not None))
+  want_pos_grad = torch.is_grad_enabled() and not isinstance(grad_out, ShFactorCollector) and \
+      (positions.requires_grad or (grad_out is not None and grad_out[1] is not None))
   return _SHFn.apply(sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad)

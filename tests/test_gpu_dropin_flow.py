@@ -108,3 +108,20 @@ def test_reference_call_pattern_matches_oracle_flow(autocast, tol):
     assert rel_err(pa.grad, pb.grad) < tol, na
   # the alpha_logit gradient has a component that arrives only through points.visible.opacity (reg_loss)
   assert params["alpha_logit"].grad.abs().max() > 0
+
+
+def test_two_rank_sh_factor_exchange_matches_all_reduce():
+  """Two ranks (gloo, both on this GPU: the box has one) run bench.py's data-parallel step with the colour-gradient
+  factor exchange and compare the summed gradients with a plain all-reduce of the full gradient buffer."""
+  import json, os, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--workload", "c1", "--backend", "gloo", "--collective", "sh_factor", "--check-collective"]
+  out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+  res = json.loads(line)
+  assert res["n_gpus"] == 2 and res["config"]["cameras_per_step"] == 2
+  assert res["config"]["collective_check_rel_err"] < 1e-5

@@ -311,3 +311,38 @@ def test_half_precision_colours_from_autocast_mlp():
   ra.image.sum().backward(); rb.image.sum().backward()
   assert f16.grad.dtype == torch.float16
   assert torch.allclose(f16.grad.float(), fref.grad, rtol=2e-3, atol=1e-3)
+
+
+def test_sh_factor_exchange_equals_gradient_sum():
+  """Data-parallel SH gradient via colour-gradient factors (distributed.exchange_sh_factors): recording (M,3) colour
+  gradients per camera and rebuilding sum_c g_c (x) Y_c in one fused pass must equal accumulating the per-camera
+  coefficient gradients (what an all-reduce of d_sh would deliver), for the coefficient AND the position gradient."""
+  from splat_trainer_amd.distributed import exchange_sh_factors
+  g, cams = synthetic.scene_b(20_003, 256, 160, sh_degree=3, seed=6, radius=1.5)
+  dev = "cuda"
+  names = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
+
+  def leaves():
+    return [getattr(g, n).clone().to(dev).requires_grad_(True) for n in names]
+
+  def scene_of(ps):
+    return sta.Gaussians3D(position=ps[0], log_scaling=ps[1], rotation=ps[2], alpha_logit=ps[3], feature=ps[4])
+
+  pa = leaves()
+  for cam in cams[:3]:
+    r = sta.render_gaussians(scene_of(pa), cam.to(dev), CFG, use_sh=True)
+    ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+  assert r.points.idx.shape[0] < 20_003                       # culling: the factors are scattered by index
+  pb = leaves()
+  col = sta.ShFactorCollector()
+  for cam in cams[:3]:
+    r = sta.render_gaussians(scene_of(pb), cam.to(dev), CFG, use_sh=True, sh_collector=col)
+    ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+  assert pb[4].grad is None and len(col.items) == 3
+  d_sh = torch.zeros_like(pb[4])
+  d_pos = pb[0].grad.clone()                                   # projection part arrived through autograd
+  exchange_sh_factors(col, [0, 1, 2], 3, pb[4], pb[0], d_sh, d_pos)
+  assert rel_err(d_sh, pa[4].grad) < 2e-6
+  assert rel_err(d_pos, pa[0].grad) < 2e-6
+  for i in (1, 2, 3):                                          # the two SH forward variants (with / without the saved
+    assert rel_err(pb[i].grad, pa[i].grad) < 1e-5              # Jacobian) may differ in the last bit of a colour

@@ -55,7 +55,7 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 7) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 8) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -174,6 +174,22 @@ int gsr_ssim_backward(const float* img1, const float* img2, const int64_t* strid
                       const int64_t* strides_out_host, int32_t B, int32_t C, int32_t H, int32_t W, const float* dm_dmu1,
                       const float* dm_dm11, const float* dm_dm12, const float* grad_scale_dev, float* d_img1,
                       void* stream);
+
+/* ---- optimizer stage next to the path: sparse visibility-aware Adam / LaProp step on the
+ *      rows a batch has seen; replaces the Taichi kernels behind taichi_splatting.optim.ParameterClass.step
+ *      (splat_trainer/scene/mlp_scene.py:214-230, options :58-60, groups config/scene/mlp.yaml:8-14).  Arithmetic:
+ *      oracle/optim_oracle.py. ------------------------------------------------------------------------------------ */
+/* Once per step.  indexes [M] int64, unique; visibility [M] or NULL (weight 1, no normalisation; vis_avg unused);
+ * step [N] and vis_avg [N] are per-point state updated in place; row_scale_out [M,4] feeds gsr_opt_step. */
+int gsr_opt_point_weights(const int64_t* indexes, const float* visibility, int64_t M, float* step, float* vis_avg,
+                          float beta1, float beta2, float vis_beta, float vis_smooth, int32_t bias_correction,
+                          float* row_scale_out, void* stream);
+/* Once per parameter group, in place on rows `indexes` of param / exp_avg [N,D] and exp_avg_sq ([N,D] for type 0,
+ * [N] otherwise).  type: 0 scalar, 1 vector (one second moment per row), 2 local_vector (D = 3, basis [M,3,3]
+ * row-major: gradient and update expressed in the splat's own axes).  algo: 0 Adam, 1 LaProp.  grad_clip <= 0: off. */
+int gsr_opt_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* indexes,
+                 const float* row_scale, const float* basis, int64_t M, int32_t D, int32_t type, int32_t algo, float lr,
+                 float beta1, float beta2, float eps, float grad_clip, void* stream);
 
 #ifdef __cplusplus
 }

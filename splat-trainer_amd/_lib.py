@@ -11,7 +11,7 @@ import threading
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GsrRasterParamsC(C.Structure):
@@ -54,6 +54,8 @@ PROTOTYPES = {
     "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p]),
     "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p]),
+    "gsr_opt_point_weights": (C.c_int, [_p, _p, _i64, _p, _p, _f, _f, _f, _f, _i32, _p, _p]),
+    "gsr_opt_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f, _f, _f, _f, _f, _p]),
     "gsr_ssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "gsr_ssim_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gsr_ssim_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),

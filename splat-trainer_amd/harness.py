@@ -9,10 +9,12 @@ end to end.  It restates, for the harness only, the consumers the reference keep
   split_gaussians_uniform ........ splat_trainer/gaussians/split.py:87-113  (k = 2, +/-0.7 sigma along a sampled
                                    axis, that axis scaled by 1/sqrt(2))
   scene.split_and_prune .......... splat_trainer/scene/mlp_scene.py:301-310 (keep_mask rows + appended splits)
-  scene.step (subset) ............ mlp_scene.py:236-237 (renormalise quaternions, clamp log_scaling to [-8, 8])
+  scene.step ..................... mlp_scene.py:214-239 (visible rows -> basis -> points.step(visibility, indexes,
+                                   basis); renormalise quaternions, clamp log_scaling to [-8, 8]; zero_grad)
+  scene.add_rendering ............ mlp_scene.py:241-244 (visible[idx] += visibility)
 
-The optimizer is plain torch Adam (the reference's sparse visibility-aware LaProp lives in taichi_splatting
-and is SURVEY.md section 8f "next").  Nothing here is on the measured hot path.
+The optimizer is optim.ParameterClass with VisibilityAwareLaProp and the reference's group types
+(config/scene/mlp.yaml:8-14).  Nothing here is on the measured hot path.
 """
 from __future__ import annotations
 
@@ -26,6 +28,7 @@ import torch.nn.functional as F
 
 from .controller_math import PointState, find_split_prune_indexes
 from .data_types import CameraParams, Gaussians3D, RasterConfig
+from .optim import ParameterClass, VisibilityAwareLaProp
 from .renderer import render_gaussians
 
 PARAM_NAMES = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
@@ -73,40 +76,59 @@ class TrainLog:
 
 
 class MiniTrainer:
-  """Replicated-parameter training loop: batch of cameras -> grads -> Adam -> (every ``densify_every`` its)
-  TargetController-style split/prune with buffer re-sizing."""
+  """Replicated-parameter training loop: batch of cameras -> grads -> sparse visibility-aware LaProp step -> (every
+  ``densify_every`` its) TargetController-style split/prune with buffer re-sizing (optimizer state rides along)."""
 
   def __init__(self, gaussians: Gaussians3D, cameras: Sequence[CameraParams], targets: Sequence[torch.Tensor],
                config: Optional[RasterConfig] = None, lr: float = 1e-3, densify_every: int = 25,
                target_points: Optional[int] = None, prune_rate: float = 0.025, min_views: int = 5,
-               max_scale_px: float = 200.0, total_steps: int = 100, seed: int = 0):
+               max_scale_px: float = 200.0, total_steps: int = 100, seed: int = 0, optimizer=VisibilityAwareLaProp):
     self.config = config or RasterConfig(compute_visibility=True, compute_point_heuristic=True)
     self.cameras, self.targets = list(cameras), list(targets)
-    self.params = {n: getattr(gaussians, n).detach().clone().requires_grad_(True) for n in PARAM_NAMES}
+    self.device = gaussians.position.device
+    tensors = {n: getattr(gaussians, n).detach().clone() for n in PARAM_NAMES}
+    tensors["visible"] = torch.zeros(gaussians.position.shape[0], device=self.device)       # mlp_scene.py:75
+    # LaProp steps are ~lr per iteration whatever the gradient scale; ratios between groups as in mlp.yaml:8-14
+    groups = dict(position=dict(lr=30 * lr, type="local_vector"), log_scaling=dict(lr=8 * lr),
+                  rotation=dict(lr=1 * lr, type="vector"), alpha_logit=dict(lr=10 * lr), feature=dict(lr=4 * lr))
+    self.points = ParameterClass(tensors, groups, optimizer=optimizer, betas=(0.8, 0.95), vis_beta=0.999,
+                                 vis_smooth=0.01, bias_correction=True, grad_clip=2.0)      # mlp.yaml:25-31
     self.lr, self.densify_every, self.total_steps = lr, densify_every, total_steps
     self.target_points = target_points or int(1.1 * gaussians.position.shape[0])
     self.prune_rate, self.min_views, self.max_scale_px = prune_rate, min_views, max_scale_px
-    self.device = gaussians.position.device
     self.gen = torch.Generator(device=self.device).manual_seed(seed)
     self.state = PointState.new_zeros(self.num_points, self.device)
     self.step_idx = 0
     self.log = TrainLog()
-    self._new_optimizer()
 
   @property
   def num_points(self) -> int:
-    return self.params["position"].shape[0]
+    return self.points.num_points
 
-  def _new_optimizer(self):
-    self.opt = torch.optim.Adam([dict(params=[self.params[n]], lr=self.lr * (0.1 if n == "feature" else 1.0))
-                                 for n in PARAM_NAMES])
+  @property
+  def params(self) -> dict:
+    return {n: self.points.tensors[n] for n in PARAM_NAMES}
 
   def scene(self) -> Gaussians3D:
     return Gaussians3D(**self.params)
 
+  @torch.no_grad()
+  def optimizer_step(self):
+    """mlp_scene.py:214-239."""
+    pts = self.points
+    vis_idx = pts.visible.nonzero().squeeze(1)
+    basis = point_basis(pts.log_scaling.detach()[vis_idx], pts.rotation.detach()[vis_idx]).contiguous()
+    if pts.optimizer.visibility_aware:
+      pts.step(visibility=pts.visible[vis_idx], indexes=vis_idx, basis=basis)
+    else:
+      pts.step(indexes=vis_idx, basis=basis)
+    pts.rotation.data = F.normalize(pts.rotation.data, dim=1)
+    pts.log_scaling.data.clamp_(min=-8, max=8)
+    pts.visible.zero_()
+    pts.zero_grad()
+
   def training_step(self) -> float:
     """trainer.py:531-545: evaluate_backward_with over the batch, then the optimizer step."""
-    self.opt.zero_grad(set_to_none=True)
     total = 0.0
     for cam, target in zip(self.cameras, self.targets):
       with torch.enable_grad():
@@ -117,11 +139,9 @@ class MiniTrainer:
         loss.backward()
       with torch.no_grad():
         self.state.add_rendering(r)                                    # point_state.py:34-50 (camera order)
+        self.points.visible[r.points.idx] += r.points.visibility       # mlp_scene.py:244
       total += float(loss.item())
-    self.opt.step()
-    with torch.no_grad():                                              # mlp_scene.py:236-237
-      self.params["rotation"].data = F.normalize(self.params["rotation"].data, dim=1)
-      self.params["log_scaling"].data.clamp_(min=-8, max=8)
+    self.optimizer_step()
     self.step_idx += 1
     self.log.losses.append(total / len(self.cameras))
     self.log.num_points.append(self.num_points)
@@ -138,12 +158,12 @@ class MiniTrainer:
     self.log.mask_digests.append(digest)
     keep_mask = ~(split_mask | prune_mask)
     split_idx = split_mask.nonzero().squeeze(1)
-    rows = {n: p.data for n, p in self.params.items()}
-    splits = split_gaussians_uniform({n: t_[split_idx] for n, t_ in rows.items()}, k=2, random_axis=True,
-                                     generator=self.gen)
-    self.params = {n: torch.cat([rows[n][keep_mask], splits[n]]).contiguous().requires_grad_(True) for n in PARAM_NAMES}
+    # mlp_scene.py:301-310: children from the split rows, kept rows (with their optimizer state), children appended
+    rows = {n: t_.detach()[split_idx] for n, t_ in self.points.tensors.items()}
+    splits = split_gaussians_uniform({n: rows[n] for n in PARAM_NAMES}, k=2, random_axis=True, generator=self.gen)
+    splits["visible"] = rows["visible"].repeat_interleave(2, dim=0)
+    self.points = self.points[keep_mask].append_tensors(splits)
     self.state = PointState.new_zeros(self.num_points, self.device)   # target_controller.py:120-122
-    self._new_optimizer()                                             # optimizer state is re-created (harness)
 
   def train(self, steps: int) -> TrainLog:
     for _ in range(steps):

@@ -9,6 +9,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 from oracle import torch_oracle as oracle  # noqa: E402  (test infrastructure only)
+from oracle import optim_oracle as oracle_optim  # noqa: E402,F401
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:

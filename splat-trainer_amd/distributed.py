@@ -87,26 +87,37 @@ def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank
   from . import _lib
   lib = _lib.load()
   N, _, K = sh_features.shape
-  dev = sh_features.device
-  G = torch.zeros(cameras_per_rank, N, 3, dtype=torch.float32, device=dev)
-  cams = torch.zeros(cameras_per_rank, 3, dtype=torch.float32, device=dev)
-  assert len(collector.items) == len(camera_slots)
-  for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
-    G[slot].index_copy_(0, idx, dcol)
-    cams[slot].copy_(cam)
-  ws = dist.get_world_size(group) if dist.is_initialized() else 1
-  if ws > 1:
-    G_all = torch.empty(ws * cameras_per_rank, N, 3, dtype=torch.float32, device=dev)
-    cams_all = torch.empty(ws * cameras_per_rank, 3, dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(G_all, G, group=group)
-    dist.all_gather_into_tensor(cams_all, cams, group=group)
-  else:
-    G_all, cams_all = G, cams
+  G_all, cams_all = gather_sh_factors(collector, camera_slots, cameras_per_rank, N, group=group)
   ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
   _lib.check(lib.gsr_sh_backward_multi(ptr(G_all), ptr(cams_all), G_all.shape[0], ptr(sh_features.detach()),
                                        ptr(positions.detach()), N, K, ptr(d_sh), ptr(d_pos),
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_sh_backward_multi")
   collector.clear()
+
+
+def gather_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, num_points: int, group=None):
+  """The collective half of ``exchange_sh_factors``: scatters this rank's recorded colour gradients to dense
+  (cameras_per_rank, N, 3) rows and all-gathers them with the camera positions.  Returns
+  (G_all (ws * cameras_per_rank, N, 3), camera_positions (ws * cameras_per_rank, 3)), rank-major, identical on every
+  rank.  Pure torch + torch.distributed (works on gloo/CPU)."""
+  if len(collector.items) != len(camera_slots):
+    raise ValueError(f"{len(collector.items)} recorded cameras but {len(camera_slots)} slots")
+  if len(collector.items) > cameras_per_rank:
+    raise ValueError("more recorded cameras than cameras_per_rank")
+  dev = collector.items[0][1].device if collector.items else None
+  G = torch.zeros(cameras_per_rank, num_points, 3, dtype=torch.float32, device=dev)
+  cams = torch.zeros(cameras_per_rank, 3, dtype=torch.float32, device=dev)
+  for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
+    G[slot].index_copy_(0, idx, dcol)
+    cams[slot].copy_(cam)
+  ws = dist.get_world_size(group) if dist.is_initialized() else 1
+  if ws == 1:
+    return G, cams
+  G_all = torch.empty(ws * cameras_per_rank, num_points, 3, dtype=torch.float32, device=dev)
+  cams_all = torch.empty(ws * cameras_per_rank, 3, dtype=torch.float32, device=dev)
+  dist.all_gather_into_tensor(G_all, G, group=group)
+  dist.all_gather_into_tensor(cams_all, cams, group=group)
+  return G_all, cams_all
 
 
 def gather_point_stats(local: List[dict], num_cameras: int, group=None) -> List[dict]:

@@ -86,3 +86,53 @@ def test_grad_bucket_layout():
   assert ps[0].grad.data_ptr() == b.views[0].data_ptr()      # autograd accumulated in place
   b.zero()
   assert b.flat.abs().sum() == 0 and b.extra.shape == (7,)
+
+
+def _factor_worker(rank, world, port, out_path):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from oracle import torch_oracle as oracle
+  from splat_trainer_amd.distributed import gather_sh_factors, shard_cameras
+  from splat_trainer_amd.sh import ShFactorCollector
+  g, cams = _scene()
+  n = g.position.shape[0]
+  col = ShFactorCollector()
+  mine = shard_cameras(len(cams), rank, world)
+  for j in mine:                                  # what _SHFn.backward records: (visible rows, d_colour, camera position)
+    gen = torch.Generator().manual_seed(50 + j)
+    idx = torch.randperm(n, generator=gen)[: n // 2].sort().values
+    col.items.append((idx, torch.randn(idx.numel(), 3, generator=gen), cams[j].camera_position.float()))
+  G_all, cams_all = gather_sh_factors(col, list(range(len(mine))), len(mine), n)
+  # rebuild d_sh = sum_c g_c (x) Y(dir_c) the way csrc/geometry.hip: sh_bwd_multi_kernel does, with the oracle's basis
+  d_sh = torch.zeros(n, 3, 4)
+  for c in range(G_all.shape[0]):
+    d = torch.nn.functional.normalize(g.position - cams_all[c], dim=1)
+    d_sh += G_all[c][:, :, None] * oracle.sh_basis(d, 1)[:, None, :]
+  torch.save(dict(d_sh=d_sh, G=G_all, cams=cams_all), f"{out_path}.{rank}")
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sh_factor_gather_rebuilds_the_summed_sh_gradient(tmp_path):
+  """distributed.gather_sh_factors over gloo: both ranks end with the same rank-major factor block, and the rebuilt
+  coefficient gradient equals the sum of the per-camera autograd gradients of evaluate_sh_at (oracle)."""
+  from oracle import torch_oracle as oracle
+  world, port = 2, 31000 + (os.getpid() % 2000)
+  out = str(tmp_path / "fac")
+  mp.spawn(_factor_worker, args=(world, port, out), nprocs=world, join=True)
+  r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+  assert torch.equal(r0["G"], r1["G"]) and torch.equal(r0["cams"], r1["cams"]) and torch.equal(r0["d_sh"], r1["d_sh"])
+  g, cams = _scene()
+  n = g.position.shape[0]
+  order = [0, 2, 1, 3]                                              # rank-major: rank 0 holds cameras 0, 2
+  for slot, j in enumerate(order):
+    assert torch.allclose(r0["cams"][slot], cams[j].camera_position.float())
+  sh = g.feature.clone().requires_grad_(True)
+  for j in range(4):
+    gen = torch.Generator().manual_seed(50 + j)
+    idx = torch.randperm(n, generator=gen)[: n // 2].sort().values
+    dcol = torch.randn(idx.numel(), 3, generator=gen)
+    col = oracle.evaluate_sh_at(sh, g.position, idx, cams[j].camera_position)
+    col.backward(dcol)
+  assert torch.allclose(r0["d_sh"], sh.grad, rtol=1e-4, atol=1e-6)

@@ -49,6 +49,12 @@ __device__ __forceinline__ v2f eval_G2(v2f q) {     // exp(-q/2) = 2^(q * -0.5*l
   return (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
 }
 
+// min(a, cmax) for a >= 0 as one v_med3_f32 per pixel (fminf would add a canonicalising v_max per operand);
+// shared by forward and backward so both take the same clamp decision.
+__device__ __forceinline__ v2f clamp_alpha2(v2f a, float cmax) {
+  return (v2f){__builtin_amdgcn_fmed3f(a.x, 0.f, cmax), __builtin_amdgcn_fmed3f(a.y, 0.f, cmax)};
+}
+
 struct Splat {            // one depth-ordered record, wave-uniform (lives in SGPRs)
   float u, v, A, B, C, op, depth, f0, f1, f2;
   uint32_t halves;        // bit h set: the splat's support reaches tile half h (from K4 emit)
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
             if (__ballot(in0 || in1) != 0ull) {
               const v2f G = eval_G2(q);
               const v2f a_raw = G * s.op;
-              v2f alpha = __builtin_elementwise_min(a_raw, GSR_V2(rp.clamp_max_alpha));
+              v2f alpha = clamp_alpha2(a_raw, rp.clamp_max_alpha);
               const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
               const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
               alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
         if (__ballot(in0 || in1) != 0ull) {
           const v2f G = eval_G2(q);
           const v2f a_raw = G * s.op;
-          v2f alpha = __builtin_elementwise_min(a_raw, GSR_V2(rp.clamp_max_alpha));
+          v2f alpha = clamp_alpha2(a_raw, rp.clamp_max_alpha);
           const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
           const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
           alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
   for (int o = 32; o > 0; o >>= 1) tile_last = max(tile_last, __shfl_xor(tile_last, o, 64));
   tile_last = __builtin_amdgcn_readfirstlane(tile_last);
   if (tile_last == 0) return;
-  const int slot_of_row = ((lane >> 4) & 1) * 2 + (lane >> 5);      // {0,2,1,3}[lane >> 4]
+  __shared__ float red[12 * 80];
+  const int wslot = (lane >> 4) * 20 + (lane & 15);                  // my cell inside a value's 80-word row
+  const int rslot = lane < 48 ? (lane >> 2) * 80 + (lane & 3) * 20 : 0;   // reader 4k+p: quarter p of value k
 
   for (int cbase = ((tile_last - 1) >> 6) << 6; cbase >= 0; cbase -= 64) {
     const int n = min(64, tile_last - cbase);
@@ -333,15 +335,27 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
       float du = du2.x + du2.y, dv = dv2.x + dv2.y, dA = dA2.x + dA2.y, dB = dB2.x + dB2.y, dC = dC2.x + dC2.y;
       float dop = dop2.x + dop2.y, prune = prune2.x + prune2.y, split = split2.x + split2.y;
       float df[3] = {df2[0].x + df2[0].y, df2[1].x + df2[1].y, df2[2].x + df2[2].y};
-      // fixed-order transposing wave reduction: lane 16r+15 of tj ends with the total of slot 4j + {0,2,1,3}[r]
-      const float vals[12] = {du, dv, dA, dB, dC, dop, prune, split, df[0], df[1], df[2], 0.f};
-      float t0, t1, t2;
-      gsr_wave_sum12_transposed(vals, t0, t1, t2);
-      if ((lane & 15) == 15) {
-        float* out = partial + (size_t)GSR_PARTIAL_FLOATS * inst_j + slot_of_row;
-        out[0] = t0;
-        out[4] = t1;
-        out[8] = t2;
+      // Per-pair reduction of the 11 sums over the tile's 256 pixels THROUGH LDS (the wave owns the block's LDS, no
+      // barrier): every lane parks its 11 values, value-major, then lane 4k+p adds quarter p (16 lanes) of value k with
+      // packed adds and two quad DPP steps finish it -- 8 packed adds + 3 scalar ops on the VALU instead of 9 permlane
+      // swaps + 9 adds + 12 DPP steps of the register-only transposing tree (the VALU is the binding unit here, the LDS
+      // pipe is idle otherwise).  Rows are padded (16 -> 20 words per quarter, 80 per value) so that the 128-bit reads
+      // of 8 consecutive lanes fall into 32 distinct banks.  Fixed association order => bit-reproducible.
+      {
+        float* wr = red + wslot;
+        wr[0 * 80] = du; wr[1 * 80] = dv; wr[2 * 80] = dA; wr[3 * 80] = dB; wr[4 * 80] = dC; wr[5 * 80] = dop;
+        wr[6 * 80] = prune; wr[7 * 80] = split; wr[8 * 80] = df[0]; wr[9 * 80] = df[1]; wr[10 * 80] = df[2];
+        const float4* rd = reinterpret_cast<const float4*>(red + rslot);
+        const float4 a = rd[0], b = rd[1], c = rd[2], d = rd[3];
+        const v2f t = (((v2f){a.x, a.y} + (v2f){a.z, a.w}) + ((v2f){b.x, b.y} + (v2f){b.z, b.w})) +
+                      (((v2f){c.x, c.y} + (v2f){c.z, c.w}) + ((v2f){d.x, d.y} + (v2f){d.z, d.w}));
+        float tot = t.x + t.y;
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                     : "+v"(tot));
+        if (lane < 44 && (lane & 3) == 0) partial[(size_t)GSR_PARTIAL_FLOATS * inst_j + (lane >> 2)] = tot;
       }
       if (!more) break;
     }

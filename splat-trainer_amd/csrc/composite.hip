@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
               if (C > 1) col2[h][1] = __builtin_elementwise_fma(w, GSR_V2(s.f1), col2[h][1]);
               if (C > 2) col2[h][2] = __builtin_elementwise_fma(w, GSR_V2(s.f2), col2[h][2]);
               wsum2 += w;
-              T2[h] = T2[h] * (GSR_V2(1.f) - alpha);
+              T2[h] = T2[h] - w;                                 // T (1 - alpha), with w = alpha T already formed
               if (hit0) lastc[2 * h] = idx;
               if (hit1) lastc[2 * h + 1] = idx;
               if (MEDIAN) {

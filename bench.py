@@ -164,7 +164,7 @@ def main():
   factor_mode = args.collective == "sh_factor"
   # + the per-point `visible` accumulator (mlp_scene.py:244)
   bucket = GradBucket(params[:4] if factor_mode else params, world, extra=N)
-  feature_grad = torch.zeros_like(feature) if factor_mode else None
+  feature_grad = torch.empty_like(feature) if factor_mode else None
   collector = sta.ShFactorCollector() if factor_mode else None
   my_cams = [cams[j].to(dev) for j in shard_cameras(world, rank, world)]   # one camera per rank per step
   target_image = torch.full((w["h"], w["w"], 3), 0.5, device=dev)
@@ -177,7 +177,11 @@ def main():
   last = {}
 
   def step():
-    bucket.zero()
+    if factor_mode:
+      bucket.zero()
+    else:                                     # the first SH backward of the step overwrites the feature gradient
+      bucket.zero(except_views=(4,))
+      grad_out.feature_uninitialized = True
     for cam in my_cams:
       with torch.enable_grad():
         r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
@@ -187,9 +191,8 @@ def main():
       last["r"] = r
     if factor_mode:
       bucket.all_reduce(mode="all_reduce")                   # geometry gradients + visible accumulator (11+1 floats/splat)
-      feature_grad.zero_()
       exchange_sh_factors(collector, list(range(len(my_cams))), len(my_cams), feature, position, feature_grad,
-                          bucket.views[0])                   # after the reduce: adds the term of ALL cameras
+                          bucket.views[0], accumulate=False)  # after the reduce: the term of ALL cameras; d_sh overwritten
     else:
       bucket.all_reduce(mode=args.collective)
 

@@ -55,7 +55,7 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 8) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 9) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -108,13 +108,25 @@ int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const flo
                     int64_t M, int32_t K, const float* camera_pos, const float* jacobian /* [M,9] or NULL */,
                     float* d_sh_features, float* d_positions, int32_t accumulate, void* stream);
 
+/* inverse_out [N] int32: rank m of row r in the ascending list `indexes` [M], or -1 when the row is not in the list. */
+int gsr_inverse_map(const int64_t* indexes, int64_t M, int64_t N, int32_t* inverse_out, void* stream);
+/* Same gradient as gsr_sh_backward, but d_sh_features [N,3,K] is OVERWRITTEN for every scene row (zeros where the
+ * camera saw nothing): the caller needs neither a zero-filled buffer nor a read-modify-write.  inverse [N] from
+ * gsr_inverse_map, or NULL when M == N (every row visible, indexes = 0..N-1).  d_positions [N,3] (may be NULL) is
+ * accumulated ("+="). */
+int gsr_sh_backward_dense(const float* dL_dcolors, const float* sh_features, const float* positions,
+                          const int32_t* inverse, int64_t M, int64_t N, int32_t K, const float* camera_pos,
+                          const float* jacobian /* [M,9] or NULL */, float* d_sh_features, float* d_positions,
+                          void* stream);
+
 /* Multi-camera form for the data-parallel path.  dL_dcolors_dense [num_cameras, N, 3]: per-camera colour gradients
  * scattered to scene rows (all-zero rows = not visible); camera_positions [num_cameras, 3].  Adds
  * sum_c g_c (x) Y(dir_c) to d_sh_features [N,3,K] and the view-direction term to d_positions [N,3] (may be NULL),
  * cameras in index order.  Lets ranks exchange the 16x smaller colour gradients instead of all-reducing d_sh. */
 int gsr_sh_backward_multi(const float* dL_dcolors_dense, const float* camera_positions, int32_t num_cameras,
                           const float* sh_features, const float* positions, int64_t N, int32_t K, float* d_sh_features,
-                          float* d_positions, void* stream);
+                          float* d_positions, int32_t accumulate /* 0: d_sh_features is overwritten for every row */,
+                          void* stream);
 
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */
 /* depth -> sortable u32 keys */

@@ -227,6 +227,81 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// Row -> visible-rank map of an ascending index list: inv[idx[m]] = m and -1 for the rows in the gaps.  Thread m also
+// fills the gap in front of its row (the last thread the tail), so no pre-fill pass is needed.
+__global__ __launch_bounds__(256) void inverse_map_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N,
+                                                          int32_t* __restrict__ inv) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m > M) return;
+  const int64_t lo = m > 0 ? idx[m - 1] + 1 : 0;
+  const int64_t hi = m < M ? idx[m] : N;
+  for (int64_t r = lo; r < hi; ++r) inv[r] = -1;
+  if (m < M) inv[hi] = (int32_t)m;
+}
+
+// SH backward that OVERWRITES the whole (N,3,K) gradient: rows a camera did not see get zeros, so the caller needs
+// neither a zero-fill of the buffer nor a read-modify-write of the visible rows (one 4*3K-byte store per row instead of
+// fill + load + store).  A block handles 256 consecutive rows: each thread forms its row in LDS (row pitch 3K+1 words:
+// conflict-free), then the block streams the 256 rows out with fully coalesced stores.  The position gradient is
+// accumulated ("+=") as in sh_bwd_kernel<K, true>.
+template <int K>
+__global__ __launch_bounds__(256) void sh_bwd_dense_kernel(const float* __restrict__ dcol, const float* __restrict__ sh,
+                                                           const float* __restrict__ pos,
+                                                           const int32_t* __restrict__ inv, int64_t N,
+                                                           const float* __restrict__ cam_pos,
+                                                           float* __restrict__ dsh, float* __restrict__ dpos,
+                                                           const float* __restrict__ jac) {
+  constexpr int ROW = 3 * K, PITCH = ROW + 1;
+  __shared__ float s_rows[256 * PITCH];
+  const int64_t row0 = (int64_t)blockIdx.x * 256;
+  const int64_t i = row0 + threadIdx.x;
+  float* mine = s_rows + threadIdx.x * PITCH;
+  const int64_t m = (i < N) ? (inv ? (int64_t)inv[i] : i) : -1;
+  if (m >= 0) {
+    const float vx = pos[3 * i] - cam_pos[0], vy = pos[3 * i + 1] - cam_pos[1], vz = pos[3 * i + 2] - cam_pos[2];
+    const float rinv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
+    const float x = vx * rinv, y = vy * rinv, z = vz * rinv;
+    float Y[K];
+    gsr_sh_basis<K>(x, y, z, Y);
+    const float g3[3] = {dcol[3 * m], dcol[3 * m + 1], dcol[3 * m + 2]};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int k = 0; k < K; ++k) mine[ch * K + k] = g3[ch] * Y[k];
+    if (dpos != nullptr && jac != nullptr) {
+      const float* J = jac + 9 * m;
+      dpos[3 * i] += g3[0] * J[0] + g3[1] * J[3] + g3[2] * J[6];
+      dpos[3 * i + 1] += g3[0] * J[1] + g3[1] * J[4] + g3[2] * J[7];
+      dpos[3 * i + 2] += g3[0] * J[2] + g3[1] * J[5] + g3[2] * J[8];
+    } else if (dpos != nullptr && K > 1) {
+      float dYx[K], dYy[K], dYz[K];
+      gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
+      const float* c = sh + (int64_t)ROW * i;
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+          const float w = g3[ch] * c[ch * K + k];
+          gx += w * dYx[k]; gy += w * dYy[k]; gz += w * dYz[k];
+        }
+      }
+      const float dot = gx * x + gy * y + gz * z;
+      dpos[3 * i] += (gx - x * dot) * rinv;
+      dpos[3 * i + 1] += (gy - y * dot) * rinv;
+      dpos[3 * i + 2] += (gz - z * dot) * rinv;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < ROW; ++e) mine[e] = 0.f;
+  }
+  __syncthreads();
+  const int64_t rows_here = (N - row0) < 256 ? (N - row0) : 256;
+  const int total = (int)rows_here * ROW;
+  float* out = dsh + row0 * ROW;
+  for (int e = threadIdx.x; e < total; e += 256) out[e] = s_rows[(e / ROW) * PITCH + (e % ROW)];
+}
+
 // Multi-camera SH backward for the data-parallel path: instead of all-reducing the (N,3,K) coefficient gradient (81 %
 // of the gradient bytes at K = 16), ranks all-gather the (cameras,N,3) colour gradients -- 16x smaller -- and every
 // rank rebuilds  d_sh[i] = sum_c g_c[i] (x) Y(dir_c(i))  locally, cameras in index order (deterministic and identical
@@ -237,7 +312,8 @@ template <int K>
 __global__ __launch_bounds__(256) void sh_bwd_multi_kernel(const float* __restrict__ G, const float* __restrict__ cams,
                                                            int ncam, const float* __restrict__ sh,
                                                            const float* __restrict__ pos, int64_t N,
-                                                           float* __restrict__ dsh, float* __restrict__ dpos) {
+                                                           float* __restrict__ dsh, float* __restrict__ dpos,
+                                                           int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
@@ -276,13 +352,13 @@ __global__ __launch_bounds__(256) void sh_bwd_multi_kernel(const float* __restri
       gpx += (gx - x * dot) * inv; gpy += (gy - y * dot) * inv; gpz += (gz - z * dot) * inv;
     }
   }
-  if (!any) return;
+  if (!any && accumulate) return;
   float* row = dsh + (int64_t)3 * K * i;
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-    for (int k = 0; k < K; ++k) row[ch * K + k] += acc[ch][k];
-  if (dpos != nullptr && K > 1) {
+    for (int k = 0; k < K; ++k) row[ch * K + k] = accumulate ? row[ch * K + k] + acc[ch][k] : acc[ch][k];
+  if (any && dpos != nullptr && K > 1) {
     dpos[3 * i] += gpx; dpos[3 * i + 1] += gpy; dpos[3 * i + 2] += gpz;
   }
 }
@@ -299,7 +375,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 8; }
+int gsr_abi_version(void) { return 9; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -447,20 +523,50 @@ int gsr_sh_backward(const float* dL_dcolors, const float* sh_features, const flo
   return GSR_OK;
 }
 
+int gsr_inverse_map(const int64_t* indexes, int64_t M, int64_t N, int32_t* inverse_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || N < 0 || M > N || N > 0x7FFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
+  if (N == 0) return GSR_OK;
+  if (!inverse_out || (M > 0 && !indexes)) return GSR_ERR_INVALID_ARGUMENT;
+  inverse_map_kernel<<<grid_for(M + 1, 256), 256, 0, stream>>>(indexes, M, N, inverse_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_sh_backward_dense(const float* dL_dcolors, const float* sh_features, const float* positions,
+                          const int32_t* inverse, int64_t M, int64_t N, int32_t K, const float* camera_pos,
+                          const float* jacobian, float* d_sh_features, float* d_positions, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || N < 0 || M > N) return GSR_ERR_INVALID_ARGUMENT;
+  if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
+  if (N == 0) return GSR_OK;
+  if (!inverse && M != N) return GSR_ERR_INVALID_ARGUMENT;          // identity map only when every row is visible
+  if (!sh_features || !positions || !camera_pos || !d_sh_features || (M > 0 && !dL_dcolors)) return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(N, 256);
+  switch (K) {
+    case 1: sh_bwd_dense_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, inverse, N, camera_pos, d_sh_features, d_positions, jacobian); break;
+    case 4: sh_bwd_dense_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, inverse, N, camera_pos, d_sh_features, d_positions, jacobian); break;
+    case 9: sh_bwd_dense_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, inverse, N, camera_pos, d_sh_features, d_positions, jacobian); break;
+    default: sh_bwd_dense_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors, sh_features, positions, inverse, N, camera_pos, d_sh_features, d_positions, jacobian); break;
+  }
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
 int gsr_sh_backward_multi(const float* dL_dcolors_dense, const float* camera_positions, int32_t num_cameras,
                           const float* sh_features, const float* positions, int64_t N, int32_t K, float* d_sh_features,
-                          float* d_positions, void* stream_) {
+                          float* d_positions, int32_t accumulate, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (N < 0 || num_cameras < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
-  if (N == 0 || num_cameras == 0) return GSR_OK;
+  if (N == 0 || (num_cameras == 0 && accumulate)) return GSR_OK;
   if (!dL_dcolors_dense || !camera_positions || !sh_features || !positions || !d_sh_features) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(N, 256);
   switch (K) {
-    case 1: sh_bwd_multi_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
-    case 4: sh_bwd_multi_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
-    case 9: sh_bwd_multi_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
-    default: sh_bwd_multi_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions); break;
+    case 1: sh_bwd_multi_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
+    case 4: sh_bwd_multi_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
+    case 9: sh_bwd_multi_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
+    default: sh_bwd_multi_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
   }
   GSR_CHECK_LAUNCH();
   return GSR_OK;

@@ -47,6 +47,7 @@ class GradBucket:
     self.flat = torch.zeros(self.padded, dtype=torch.float32, device=dev)
     self.views = [self.flat[o:o + n].view_as(p) for p, n, o in zip(self.params, sizes, starts)]
     self.extra = self.flat[starts[-1]:starts[-1] + extra]   # e.g. the per-point `visible` accumulator
+    self._starts = starts
     self.attach()
 
   def attach(self):
@@ -54,8 +55,20 @@ class GradBucket:
     for p, v in zip(self.params, self.views):
       p.grad = v
 
-  def zero(self):
-    self.flat.zero_()
+  def zero(self, except_views: Sequence[int] = ()):
+    """Zero-fills the buffer; ``except_views`` lists parameter slots to leave alone (e.g. the feature gradient when
+    ``GradOut.feature_uninitialized`` lets the SH backward overwrite it)."""
+    if not except_views:
+      self.flat.zero_()
+      return
+    cuts = sorted((self._starts[i], self._starts[i] + self.params[i].numel()) for i in except_views)
+    at = 0
+    for lo, hi in cuts:
+      if lo > at:
+        self.flat[at:lo].zero_()
+      at = hi
+    if at < self.flat.numel():
+      self.flat[at:].zero_()
 
   def all_reduce(self, group=None, mode: str = "all_reduce"):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -71,10 +84,12 @@ class GradBucket:
 
 
 def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, sh_features: torch.Tensor,
-                        positions: torch.Tensor, d_sh: torch.Tensor, d_pos: Optional[torch.Tensor], group=None):
+                        positions: torch.Tensor, d_sh: torch.Tensor, d_pos: Optional[torch.Tensor], group=None,
+                        accumulate: bool = True):
   """All-gathers the colour-gradient factors recorded by a ``ShFactorCollector`` and adds the summed SH coefficient
   gradient of ALL cameras of the batch to ``d_sh`` (N,3,K) -- and the view-direction term to ``d_pos`` (N,3) -- on every
-  rank.  ``d_sh`` / ``d_pos`` therefore must NOT be all-reduced afterwards.
+  rank.  ``d_sh`` / ``d_pos`` therefore must NOT be all-reduced afterwards.  ``accumulate=False``: ``d_sh`` is
+  overwritten row for row instead (no zero-fill by the caller, no read of the old contents).
 
   Why: at K = 16 the coefficient gradient is 48 of the 59 floats per splat that a gradient all-reduce moves; its
   per-camera factors (3 floats per splat + 3 per camera) are 16x smaller, positions and coefficients are replicated,
@@ -90,7 +105,7 @@ def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank
   G_all, cams_all = gather_sh_factors(collector, camera_slots, cameras_per_rank, N, group=group)
   ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
   _lib.check(lib.gsr_sh_backward_multi(ptr(G_all), ptr(cams_all), G_all.shape[0], ptr(sh_features.detach()),
-                                       ptr(positions.detach()), N, K, ptr(d_sh), ptr(d_pos),
+                                       ptr(positions.detach()), N, K, ptr(d_sh), ptr(d_pos), int(accumulate),
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_sh_backward_multi")
   collector.clear()
 

@@ -113,11 +113,18 @@ class GradOut:
   the backward kernels add ("+=") their rows straight into these N-sized buffers -- typically the parameters'
   ``.grad`` tensors, which is where the reference accumulates over the cameras of a batch
   (trainer.py:500-514, mlp_scene.py:155-161) -- and autograd receives no gradient for those inputs.  This
-  removes the zero-fill + dense add of N-sized temporaries per camera.  Default (None): plain autograd."""
+  removes the zero-fill + dense add of N-sized temporaries per camera.  Default (None): plain autograd.
 
-  def __init__(self, position=None, log_scaling=None, rotation=None, alpha_logit=None, feature=None):
+  ``feature_uninitialized = True`` tells the next SH backward that ``feature`` (by far the largest buffer, 3K of the
+  3K+11 floats per splat) holds nothing worth keeping: it is then overwritten row for row -- zeros where the camera saw
+  nothing -- instead of zero-filled by the caller and added to, and the flag is cleared.  Set it before the first
+  camera of a batch and skip ``feature`` in the zero-fill."""
+
+  def __init__(self, position=None, log_scaling=None, rotation=None, alpha_logit=None, feature=None,
+               feature_uninitialized: bool = False):
     self.position, self.log_scaling, self.rotation = position, log_scaling, rotation
     self.alpha_logit, self.feature = alpha_logit, feature
+    self.feature_uninitialized = feature_uninitialized
 
   def _check(self, name, like):
     t = getattr(self, name)
@@ -387,7 +394,7 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
     if sh_collector is not None:            # data-parallel: exchange colour-gradient factors, not d_sh (sh.py)
       sh_out = sh_collector
     elif grad_out is not None:
-      sh_out = (grad_out._check("feature", gaussians.feature), grad_out._check("position", gaussians.position))
+      sh_out = (grad_out._check("feature", gaussians.feature), grad_out._check("position", gaussians.position), grad_out)
     feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_params.camera_position,
                            grad_out=sh_out)
   else:

@@ -66,17 +66,30 @@ class _SHFn(torch.autograd.Function):
     if isinstance(go, ShFactorCollector):    # data-parallel factor exchange: keep only the colour gradient
       go.items.append((idx, d_out.detach().to(torch.float32).contiguous(), cam))
       return None, None, None, None, None, None
+    g = d_out.detach().to(torch.float32).contiguous() if M > 0 else None
+    owner = go[2] if (go is not None and len(go) > 2) else None
+    overwrite = go is None or (owner is not None and owner.feature_uninitialized)
     if go is not None:                       # fused "+=" into caller-owned buffers (see renderer.GradOut)
-      d_sh, d_pos = go
+      d_sh, d_pos = go[0], go[1]
     else:
-      alloc = torch.empty if M == N else torch.zeros
-      d_sh = alloc(N, 3, K, dtype=torch.float32, device=pos.device)
+      d_sh = torch.empty(N, 3, K, dtype=torch.float32, device=pos.device)
       d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[1] else None
-    if M > 0:
-      g = d_out.detach().to(torch.float32).contiguous()
-      _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(ctx.jac),
-                                     _ptr(d_sh), _ptr(d_pos), 1 if go is not None else 0, _stream()),
-                 "gsr_sh_backward")
+    if overwrite and N > 0 and (M == N or 8 * M >= N):
+      # every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no read-modify-write
+      inv = None
+      if M < N:
+        inv = torch.empty(N, dtype=torch.int32, device=pos.device)
+        _lib.check(lib.gsr_inverse_map(_ptr(idx), M, N, _ptr(inv), _stream()), "gsr_inverse_map")
+      _lib.check(lib.gsr_sh_backward_dense(_ptr(g), _ptr(sh), _ptr(pos), _ptr(inv), M, N, K, _ptr(cam), _ptr(ctx.jac),
+                                           _ptr(d_sh), _ptr(d_pos), _stream()), "gsr_sh_backward_dense")
+    else:
+      if overwrite:
+        d_sh.zero_()
+      if M > 0:
+        _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(ctx.jac),
+                                       _ptr(d_sh), _ptr(d_pos), 1, _stream()), "gsr_sh_backward")
+    if owner is not None:
+      owner.feature_uninitialized = False
     if go is not None:
       return None, None, None, None, None, None
     return (d_sh.to(ctx.in_dtypes[0]), d_pos.to(ctx.in_dtypes[1]) if d_pos is not None else None,
@@ -90,7 +103,8 @@ def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: 
   colour_c = 0.5 + sum_k sh[idx, c, k] * Y_k(normalize(positions[idx] - camera_pos)), K in {1,4,9,16}
   (degrees 0..3, basis order k = n(n+1)+m as splat_trainer/scene/mlp/rsh.py).  Differentiable wrt
   ``sh_features`` and, through the view direction, ``positions``; the caller clamps (transfer_sh.py:50).
-  ``grad_out=(d_sh, d_positions)``: optional fused accumulation, see ``renderer.GradOut``."""
+  ``grad_out=(d_sh, d_positions[, owner])``: optional fused accumulation, see ``renderer.GradOut`` (when
+  ``owner.feature_uninitialized`` is set, ``d_sh`` is overwritten row for row instead of added to, and the flag is cleared)."""
   for t in (sh_features, positions, indexes, camera_pos):
     if not t.is_cuda:
       raise _lib.GsplatHipError("evaluate_sh_at runs only on a HIP device; there is no CPU fallback")

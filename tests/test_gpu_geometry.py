@@ -95,3 +95,54 @@ def test_empty_inputs():
   out = sta.evaluate_sh_at(torch.zeros(5, 3, 4).cuda(), torch.zeros(5, 3).cuda(),
                            torch.zeros(0, dtype=torch.int64).cuda(), torch.zeros(3).cuda())
   assert out.shape == (0, 3)
+
+
+@pytest.mark.parametrize("K,frac", [(16, 0.6), (9, 0.3), (4, 1.0), (1, 0.6), (16, 0.05)])
+def test_sh_backward_overwrite_paths_match_accumulate(K, frac):
+  """GradOut.feature_uninitialized / plain autograd: d_sh is overwritten row for row (gsr_inverse_map +
+  gsr_sh_backward_dense; zero-fill + accumulate when fewer than 1/8 of the rows are visible) -- same values as adding
+  into a zero-filled buffer, zeros in the rows the camera did not see, stale buffer contents gone."""
+  torch.manual_seed(K)
+  n = 4099
+  sh = torch.randn(n, 3, K, device="cuda")
+  pos = torch.randn(n, 3, device="cuda") * 2
+  cam = torch.tensor([0.3, -0.2, 5.0], device="cuda")
+  idx = (torch.rand(n, device="cuda") < frac).nonzero().squeeze(1) if frac < 1.0 else torch.arange(n, device="cuda")
+  g = torch.randn(idx.shape[0], 3, device="cuda")
+  # reference: accumulate into zero-filled caller buffers
+  d_sh_a, d_pos_a = torch.zeros_like(sh), torch.zeros_like(pos)
+  out = sta.evaluate_sh_at(sh.requires_grad_(True), pos.requires_grad_(True), idx, cam, grad_out=(d_sh_a, d_pos_a))
+  out.backward(g)
+  # overwrite into a buffer full of stale values
+  owner = sta.GradOut(feature_uninitialized=True)
+  d_sh_b, d_pos_b = torch.full_like(sh, 7.0), torch.zeros_like(pos)
+  out = sta.evaluate_sh_at(sh, pos, idx, cam, grad_out=(d_sh_b, d_pos_b, owner))
+  out.backward(g)
+  assert owner.feature_uninitialized is False
+  assert rel_err(d_sh_b, d_sh_a) < 1e-6 and rel_err(d_pos_b, d_pos_a) < 1e-6
+  unseen = torch.ones(n, dtype=torch.bool, device="cuda")
+  unseen[idx] = False
+  assert float(d_sh_b[unseen].abs().max()) == 0.0 if unseen.any() else True
+  # a second camera then accumulates on top
+  out = sta.evaluate_sh_at(sh, pos, idx, cam, grad_out=(d_sh_b, d_pos_b, owner))
+  out.backward(g)
+  assert rel_err(d_sh_b, 2 * d_sh_a) < 1e-6
+  # plain autograd takes the same overwrite path
+  sh2, pos2 = sh.detach().clone().requires_grad_(True), pos.detach().clone().requires_grad_(True)
+  sta.evaluate_sh_at(sh2, pos2, idx, cam).backward(g)
+  assert rel_err(sh2.grad, d_sh_a) < 1e-6 and rel_err(pos2.grad, d_pos_a) < 1e-6
+
+
+def test_inverse_map_edges():
+  import ctypes as C
+  from splat_trainer_amd import _lib
+  lib = _lib.load()
+  st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+  for n, rows in [(10, [0, 1, 2, 9]), (10, [3]), (7, []), (5, [0, 1, 2, 3, 4]), (4000, list(range(17, 4000, 13)))]:
+    idx = torch.tensor(rows, dtype=torch.int64, device="cuda")
+    inv = torch.full((n,), 12345, dtype=torch.int32, device="cuda")
+    _lib.check(lib.gsr_inverse_map(C.c_void_p(idx.data_ptr()) if rows else None, len(rows), n, C.c_void_p(inv.data_ptr()), st),
+               "gsr_inverse_map")
+    want = torch.full((n,), -1, dtype=torch.int32)
+    want[torch.tensor(rows, dtype=torch.int64)] = torch.arange(len(rows), dtype=torch.int32)
+    assert torch.equal(inv.cpu(), want), (n, rows[:5])

@@ -339,10 +339,14 @@ def test_sh_factor_exchange_equals_gradient_sum():
     r = sta.render_gaussians(scene_of(pb), cam.to(dev), CFG, use_sh=True, sh_collector=col)
     ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
   assert pb[4].grad is None and len(col.items) == 3
-  d_sh = torch.zeros_like(pb[4])
+  d_sh = torch.full_like(pb[4], 3.0)                           # stale contents: accumulate=False overwrites every row
   d_pos = pb[0].grad.clone()                                   # projection part arrived through autograd
-  exchange_sh_factors(col, [0, 1, 2], 3, pb[4], pb[0], d_sh, d_pos)
+  items = list(col.items)
+  exchange_sh_factors(col, [0, 1, 2], 3, pb[4], pb[0], d_sh, d_pos, accumulate=False)
   assert rel_err(d_sh, pa[4].grad) < 2e-6
   assert rel_err(d_pos, pa[0].grad) < 2e-6
+  col.items.extend(items)                                      # and the adding form on top of it
+  exchange_sh_factors(col, [0, 1, 2], 3, pb[4], pb[0], d_sh, None)
+  assert rel_err(d_sh, 2 * pa[4].grad) < 2e-6
   for i in (1, 2, 3):                                          # the two SH forward variants (with / without the saved
     assert rel_err(pb[i].grad, pa[i].grad) < 1e-5              # Jacobian) may differ in the last bit of a colour

@@ -227,9 +227,10 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   stream = _stream()
   tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
   num_tiles = tiles_x * tiles_y
-  heur = torch.zeros(2, M, dtype=torch.float32, device=dev)     # zero until backward fills them in place
-  st.prune_cost, st.split_score = heur[0], heur[1]
   st.O = 0
+
+  def heuristics(buf):
+    st.prune_cost, st.split_score = buf[0], buf[1]               # zero until backward fills them in place
 
   def blank():
     st.final_T = torch.ones(H, W, dtype=torch.float32, device=dev)
@@ -239,6 +240,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     return torch.zeros(H, W, C_, dtype=torch.float32, device=dev)
 
   if M == 0:
+    heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))
     st.screen_scale = torch.zeros(0, 2, dtype=torch.float32, device=dev)
     return blank()
   st.screen_scale = torch.empty(M, 2, dtype=torch.float32, device=dev)   # written for every splat by K4
@@ -269,7 +271,12 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     raise _lib.GsplatHipError("tile overlap count overflowed 2^31")
   st.O = O
   if O == 0:
+    heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))
     return blank()
+  # everything that must start at zero comes out of ONE zero-filled allocation (one fill launch instead of three)
+  n_vis = O if need_vis_partial else 0
+  zeros = torch.zeros(2 * M + 2 * num_tiles + n_vis, dtype=torch.float32, device=dev)
+  heuristics(zeros[:2 * M].view(2, M))
   # K6 writes every pixel of every tile (an empty tile writes colour 0, T 1, last 0): no zero-fills needed
   image = torch.empty(H, W, C_, dtype=torch.float32, device=dev)
   st.final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
@@ -290,10 +297,10 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
                                              _ptr(trank_b), O, 1, 0, tile_bits, _ptr(tsort_ws), tsort_bytes, stream),
                      "gsr_sort_pairs2_u32(tile)")
   sorted_keys, st.sorted_inst, st.sorted_rank = (tkeys_b, tvals_b, trank_b) if where == 1 else (tkeys_a, tvals_a, trank_a)
-  st.tile_range = torch.zeros(num_tiles, 2, dtype=torch.int32, device=dev)
+  st.tile_range = zeros[2 * M:2 * M + 2 * num_tiles].view(torch.int32).view(num_tiles, 2)
   _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), O, num_tiles, _ptr(st.tile_range), stream), "gsr_tile_ranges")
 
-  st.vis_partial = torch.zeros(O, dtype=torch.float32, device=dev) if need_vis_partial else None
+  st.vis_partial = zeros[2 * M + 2 * num_tiles:] if need_vis_partial else None
   st.pair_vis = torch.empty(O, dtype=torch.float32, device=dev) if need_vis_partial else None
   timer = KERNEL_TIMER
   if timer is not None:

@@ -190,9 +190,10 @@ def main():
       bucket.extra.index_add_(0, r.points.idx, r.points.visibility)
       last["r"] = r
     if factor_mode:
-      bucket.all_reduce(mode="all_reduce")                   # geometry gradients + visible accumulator (11+1 floats/splat)
+      # geometry gradients + visible accumulator (11+1 floats/splat); in flight while the factors are scattered
+      pending = bucket.all_reduce(mode="all_reduce", async_op=True)
       exchange_sh_factors(collector, list(range(len(my_cams))), len(my_cams), feature, position, feature_grad,
-                          bucket.views[0], accumulate=False)  # after the reduce: the term of ALL cameras; d_sh overwritten
+                          bucket.views[0], accumulate=False, after=pending)  # the term of ALL cameras; d_sh overwritten
     else:
       bucket.all_reduce(mode=args.collective)
 

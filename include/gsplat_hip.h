@@ -55,7 +55,7 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 9) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 10) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -119,13 +119,15 @@ int gsr_sh_backward_dense(const float* dL_dcolors, const float* sh_features, con
                           const float* jacobian /* [M,9] or NULL */, float* d_sh_features, float* d_positions,
                           void* stream);
 
-/* Multi-camera form for the data-parallel path.  dL_dcolors_dense [num_cameras, N, 3]: per-camera colour gradients
- * scattered to scene rows (all-zero rows = not visible); camera_positions [num_cameras, 3].  Adds
- * sum_c g_c (x) Y(dir_c) to d_sh_features [N,3,K] and the view-direction term to d_positions [N,3] (may be NULL),
- * cameras in index order.  Lets ranks exchange the 16x smaller colour gradients instead of all-reducing d_sh. */
-int gsr_sh_backward_multi(const float* dL_dcolors_dense, const float* camera_positions, int32_t num_cameras,
-                          const float* sh_features, const float* positions, int64_t N, int32_t K, float* d_sh_features,
-                          float* d_positions, int32_t accumulate /* 0: d_sh_features is overwritten for every row */,
+/* Multi-camera form for the data-parallel path.  Camera c's colour gradients, scattered to scene rows (all-zero rows
+ * = not visible), start at dL_dcolors_dense + c * dense_stride ([N,3] floats each, dense_stride >= 3N); its position
+ * (3 floats) at camera_positions + c * camera_stride.  (The strides let one all-gathered block per camera carry both:
+ * [N+1,3] with the position in the last row.)  Adds sum_c g_c (x) Y(dir_c) to d_sh_features [N,3,K] -- or overwrites
+ * every row when accumulate = 0 -- and adds the view-direction term to d_positions [N,3] (may be NULL), cameras in
+ * index order.  Lets ranks exchange the 16x smaller colour gradients instead of all-reducing d_sh. */
+int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, const float* camera_positions,
+                          int64_t camera_stride, int32_t num_cameras, const float* sh_features, const float* positions,
+                          int64_t N, int32_t K, float* d_sh_features, float* d_positions, int32_t accumulate,
                           void* stream);
 
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */

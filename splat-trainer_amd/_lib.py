@@ -11,7 +11,7 @@ import threading
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GsrRasterParamsC(C.Structure):
@@ -47,7 +47,7 @@ PROTOTYPES = {
     "gsr_project_backward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     "gsr_sh_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p]),
-    "gsr_sh_backward_multi": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p]),
+    "gsr_sh_backward_multi": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p]),
     "gsr_inverse_map": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "gsr_sh_backward_dense": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     "gsr_depth_keys": (C.c_int, [_p, _i64, _p, _p]),

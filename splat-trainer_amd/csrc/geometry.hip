@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(const float* __restri
 // the basis and the view-direction Jacobian are recomputed from them.  Rows with an all-zero colour gradient (splat
 // not seen by that camera) are skipped.
 template <int K>
-__global__ __launch_bounds__(256) void sh_bwd_multi_kernel(const float* __restrict__ G, const float* __restrict__ cams,
+__global__ __launch_bounds__(256) void sh_bwd_multi_kernel(const float* __restrict__ G, int64_t g_stride,
+                                                           const float* __restrict__ cams, int64_t cam_stride,
                                                            int ncam, const float* __restrict__ sh,
                                                            const float* __restrict__ pos, int64_t N,
                                                            float* __restrict__ dsh, float* __restrict__ dpos,
@@ -326,11 +327,12 @@ __global__ __launch_bounds__(256) void sh_bwd_multi_kernel(const float* __restri
   float gpx = 0.f, gpy = 0.f, gpz = 0.f;
   bool any = false;
   for (int c = 0; c < ncam; ++c) {
-    const float* g = G + ((int64_t)c * N + i) * 3;
+    const float* g = G + (int64_t)c * g_stride + i * 3;
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
     any = true;
-    const float vx = px - cams[3 * c], vy = py - cams[3 * c + 1], vz = pz - cams[3 * c + 2];
+    const float* cp = cams + (int64_t)c * cam_stride;
+    const float vx = px - cp[0], vy = py - cp[1], vz = pz - cp[2];
     const float inv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
     const float x = vx * inv, y = vy * inv, z = vz * inv;
     float Y[K];
@@ -375,7 +377,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 9; }
+int gsr_abi_version(void) { return 10; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -553,20 +555,20 @@ int gsr_sh_backward_dense(const float* dL_dcolors, const float* sh_features, con
   return GSR_OK;
 }
 
-int gsr_sh_backward_multi(const float* dL_dcolors_dense, const float* camera_positions, int32_t num_cameras,
-                          const float* sh_features, const float* positions, int64_t N, int32_t K, float* d_sh_features,
+int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, const float* camera_positions,
+                          int64_t camera_stride, int32_t num_cameras, const float* sh_features, const float* positions, int64_t N, int32_t K, float* d_sh_features,
                           float* d_positions, int32_t accumulate, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (N < 0 || num_cameras < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (N < 0 || num_cameras < 0 || dense_stride < 3 * N || camera_stride < 3) return GSR_ERR_INVALID_ARGUMENT;
   if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
   if (N == 0 || (num_cameras == 0 && accumulate)) return GSR_OK;
   if (!dL_dcolors_dense || !camera_positions || !sh_features || !positions || !d_sh_features) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(N, 256);
   switch (K) {
-    case 1: sh_bwd_multi_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
-    case 4: sh_bwd_multi_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
-    case 9: sh_bwd_multi_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
-    default: sh_bwd_multi_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors_dense, camera_positions, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
+    case 1: sh_bwd_multi_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
+    case 4: sh_bwd_multi_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
+    case 9: sh_bwd_multi_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
+    default: sh_bwd_multi_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
   }
   GSR_CHECK_LAUNCH();
   return GSR_OK;

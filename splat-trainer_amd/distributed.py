@@ -70,26 +70,31 @@ class GradBucket:
     if at < self.flat.numel():
       self.flat[at:].zero_()
 
-  def all_reduce(self, group=None, mode: str = "all_reduce"):
+  def all_reduce(self, group=None, mode: str = "all_reduce", async_op: bool = False):
+    """Sums the buffer over the ranks.  ``async_op=True`` (all_reduce mode only) returns the work handle instead of
+    making the current stream wait."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-      return
+      return None
     ws = dist.get_world_size(group)
     if mode == "reduce_scatter" and dist.get_backend(group) != "gloo":
       shard = self.flat.numel() // ws
       out = torch.empty(shard, dtype=torch.float32, device=self.flat.device)
       dist.reduce_scatter_tensor(out, self.flat, op=dist.ReduceOp.SUM, group=group)
       dist.all_gather_into_tensor(self.flat, out, group=group)
-    else:
-      dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+      return None
+    work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else None
 
 
 def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, sh_features: torch.Tensor,
                         positions: torch.Tensor, d_sh: torch.Tensor, d_pos: Optional[torch.Tensor], group=None,
-                        accumulate: bool = True):
+                        accumulate: bool = True, after=None):
   """All-gathers the colour-gradient factors recorded by a ``ShFactorCollector`` and adds the summed SH coefficient
   gradient of ALL cameras of the batch to ``d_sh`` (N,3,K) -- and the view-direction term to ``d_pos`` (N,3) -- on every
   rank.  ``d_sh`` / ``d_pos`` therefore must NOT be all-reduced afterwards.  ``accumulate=False``: ``d_sh`` is
-  overwritten row for row instead (no zero-fill by the caller, no read of the old contents).
+  overwritten row for row instead (no zero-fill by the caller, no read of the old contents).  ``after``: a
+  ``torch.distributed`` work handle to wait for before ``d_pos`` is touched (``GradBucket.all_reduce(async_op=True)``):
+  the scatter of the factors and their all-gather are then enqueued while that all-reduce is still in flight.
 
   Why: at K = 16 the coefficient gradient is 48 of the 59 floats per splat that a gradient all-reduce moves; its
   per-camera factors (3 floats per splat + 3 per camera) are 16x smaller, positions and coefficients are replicated,
@@ -102,37 +107,39 @@ def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank
   from . import _lib
   lib = _lib.load()
   N, _, K = sh_features.shape
-  G_all, cams_all = gather_sh_factors(collector, camera_slots, cameras_per_rank, N, group=group)
+  block = gather_sh_factors(collector, camera_slots, cameras_per_rank, N, group=group)
+  if after is not None:
+    after.wait()                     # e.g. the asynchronous all-reduce that delivers d_pos
+  stride = (N + 1) * 3
+  base = block.data_ptr()
   ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-  _lib.check(lib.gsr_sh_backward_multi(ptr(G_all), ptr(cams_all), G_all.shape[0], ptr(sh_features.detach()),
-                                       ptr(positions.detach()), N, K, ptr(d_sh), ptr(d_pos), int(accumulate),
-                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_sh_backward_multi")
+  _lib.check(lib.gsr_sh_backward_multi(C.c_void_p(base), stride, C.c_void_p(base + 4 * 3 * N), stride, block.shape[0],
+                                       ptr(sh_features.detach()), ptr(positions.detach()), N, K, ptr(d_sh), ptr(d_pos),
+                                       int(accumulate), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+             "gsr_sh_backward_multi")
   collector.clear()
 
 
 def gather_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, num_points: int, group=None):
-  """The collective half of ``exchange_sh_factors``: scatters this rank's recorded colour gradients to dense
-  (cameras_per_rank, N, 3) rows and all-gathers them with the camera positions.  Returns
-  (G_all (ws * cameras_per_rank, N, 3), camera_positions (ws * cameras_per_rank, 3)), rank-major, identical on every
-  rank.  Pure torch + torch.distributed (works on gloo/CPU)."""
+  """The collective half of ``exchange_sh_factors``: scatters this rank's recorded colour gradients to dense rows and
+  all-gathers them in ONE collective.  Every camera slot is a (N+1, 3) block: rows 0..N-1 the colour gradient of the
+  scene rows (zero where the camera saw nothing), row N the camera position.  Returns the (ws * cameras_per_rank, N+1, 3)
+  block, rank-major, identical on every rank.  Pure torch + torch.distributed (works on gloo/CPU)."""
   if len(collector.items) != len(camera_slots):
     raise ValueError(f"{len(collector.items)} recorded cameras but {len(camera_slots)} slots")
   if len(collector.items) > cameras_per_rank:
     raise ValueError("more recorded cameras than cameras_per_rank")
   dev = collector.items[0][1].device if collector.items else None
-  G = torch.zeros(cameras_per_rank, num_points, 3, dtype=torch.float32, device=dev)
-  cams = torch.zeros(cameras_per_rank, 3, dtype=torch.float32, device=dev)
+  mine = torch.zeros(cameras_per_rank, num_points + 1, 3, dtype=torch.float32, device=dev)
   for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
-    G[slot].index_copy_(0, idx, dcol)
-    cams[slot].copy_(cam)
+    mine[slot].index_copy_(0, idx, dcol)
+    mine[slot, num_points].copy_(cam)
   ws = dist.get_world_size(group) if dist.is_initialized() else 1
   if ws == 1:
-    return G, cams
-  G_all = torch.empty(ws * cameras_per_rank, num_points, 3, dtype=torch.float32, device=dev)
-  cams_all = torch.empty(ws * cameras_per_rank, 3, dtype=torch.float32, device=dev)
-  dist.all_gather_into_tensor(G_all, G, group=group)
-  dist.all_gather_into_tensor(cams_all, cams, group=group)
-  return G_all, cams_all
+    return mine
+  block = torch.empty(ws * cameras_per_rank, num_points + 1, 3, dtype=torch.float32, device=dev)
+  dist.all_gather_into_tensor(block, mine, group=group)
+  return block
 
 
 def gather_point_stats(local: List[dict], num_cameras: int, group=None) -> List[dict]:

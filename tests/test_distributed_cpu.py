@@ -102,7 +102,8 @@ def _factor_worker(rank, world, port, out_path):
     gen = torch.Generator().manual_seed(50 + j)
     idx = torch.randperm(n, generator=gen)[: n // 2].sort().values
     col.items.append((idx, torch.randn(idx.numel(), 3, generator=gen), cams[j].camera_position.float()))
-  G_all, cams_all = gather_sh_factors(col, list(range(len(mine))), len(mine), n)
+  block = gather_sh_factors(col, list(range(len(mine))), len(mine), n)      # (cameras, N+1, 3): last row = camera position
+  G_all, cams_all = block[:, :n], block[:, n]
   # rebuild d_sh = sum_c g_c (x) Y(dir_c) the way csrc/geometry.hip: sh_bwd_multi_kernel does, with the oracle's basis
   d_sh = torch.zeros(n, 3, 4)
   for c in range(G_all.shape[0]):

@@ -242,11 +242,12 @@ def main():
   alg_bytes_bwd = 40 * O + 32 * P + 36 * M                 # (S+I) O + 32 P + S M
   # HBM traffic of K7 from PMC counters cannot be collected from inside this process; the value measured with
   # rocprofv3 on the same command (separate --pmc passes) is kept under profiles/ and quoted when the workload matches
-  traffic = None
+  traffic, valu_insts = None, None
   try:
     pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c2.json")))
     if pmc.get("workload") == args.workload:
       traffic = pmc["kernels"]["K7"]["hbm_bytes_per_launch"]
+      valu_insts = pmc["kernels"]["K7"].get("SQ_INSTS_VALU")
   except Exception:   # noqa: BLE001
     traffic = None
   achieved = alg_bytes_bwd / (ms_bwd * 1e-3) / 1e9 if n_bwd else float("nan")
@@ -270,7 +271,11 @@ def main():
                      "traffic": traffic, "traffic_source": "profiles/r01_pmc_c2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, uncorrected)" if traffic else None,
                      "algorithmic_bytes_per_launch": alg_bytes_bwd,
                      "avg_launch_ms": ms_bwd, "launches_timed": n_bwd,
-                     "composite_forward_avg_ms": ms_fwd},
+                     "composite_forward_avg_ms": ms_fwd,
+                     # the kernel is bound by VALU issue, not by HBM: wave64 VALU instructions of one
+                     # launch (rocprofv3 SQ_INSTS_VALU, same PMC file) x ~4.5 SIMD cycles each over 1024 SIMDs at 2.4 GHz
+                     "valu_insts_per_launch": valu_insts,
+                     "valu_busy_frac_est": (valu_insts * 4.5 / (1024 * 2.4e9) / (ms_bwd * 1e-3)) if (valu_insts and n_bwd) else None},
     }
     if check is not None:
       out["config"]["collective_check_rel_err"] = check

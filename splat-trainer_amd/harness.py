@@ -162,7 +162,7 @@ class MiniTrainer:
     rows = {n: t_.detach()[split_idx] for n, t_ in self.points.tensors.items()}
     splits = split_gaussians_uniform({n: rows[n] for n in PARAM_NAMES}, k=2, random_axis=True, generator=self.gen)
     splits["visible"] = rows["visible"].repeat_interleave(2, dim=0)
-    self.points = self.points[keep_mask].append_tensors(splits)
+    self.points = self.points.keep_and_append(keep_mask, splits)
     self.state = PointState.new_zeros(self.num_points, self.device)   # target_controller.py:120-122
 
   def train(self, steps: int) -> TrainLog:

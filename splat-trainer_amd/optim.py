@@ -198,6 +198,32 @@ class ParameterClass:
     state = dict(step=pad(st["step"]), vis_avg=pad(st["vis_avg"]), groups=groups)
     return self._like({k: torch.cat([t.detach(), tensors[k].to(t.dtype)]) for k, t in self.tensors.items()}, state)
 
+  @torch.no_grad()
+  def keep_and_append(self, keep_mask: torch.Tensor, tensors: Dict[str, torch.Tensor]) -> "ParameterClass":
+    """``self[keep_mask].append_tensors(tensors)`` (mlp_scene.py:306-310) in one pass: the kept row indices are formed
+    once (one ``nonzero`` = one host sync instead of one per column), and every column -- parameters, extras and
+    optimizer state -- is written straight into its final buffer (one gather into the head, one copy or zero-fill of the
+    tail) instead of being masked into a temporary and concatenated."""
+    missing = set(self.tensors) - set(tensors)
+    if missing:
+      raise KeyError(f"keep_and_append: missing {sorted(missing)}")
+    keep_idx = keep_mask.nonzero().squeeze(1)
+    k, n_new = keep_idx.shape[0], next(iter(tensors.values())).shape[0]
+
+    def rebuilt(old: torch.Tensor, tail: Optional[torch.Tensor]) -> torch.Tensor:
+      out = torch.empty((k + n_new,) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
+      torch.index_select(old.detach(), 0, keep_idx, out=out[:k])
+      if tail is None:
+        out[k:].zero_()
+      else:
+        out[k:].copy_(tail)
+      return out
+
+    st = self._state
+    groups = {name: {n: rebuilt(v, None) for n, v in g.items()} for name, g in st["groups"].items()}
+    state = dict(step=rebuilt(st["step"], None), vis_avg=rebuilt(st["vis_avg"], None), groups=groups)
+    return self._like({name: rebuilt(t, tensors[name]) for name, t in self.tensors.items()}, state)
+
   def state_dict(self) -> dict:
     return dict(tensors={k: t.detach() for k, t in self.tensors.items()}, optimizer_state=self._state,
                 parameter_groups=self.parameter_groups)

@@ -91,6 +91,13 @@ def test_unseen_rows_are_untouched_and_mask_append_carry_state():
   assert grown.num_points == kept.num_points + 10 and grown.position.requires_grad and not grown.visible.requires_grad
   assert float(grown._state["step"][-10:].abs().max()) == 0.0
   assert float(grown.tensor_state["position"]["exp_avg"][-10:].abs().max()) == 0.0
+  fused = pc.keep_and_append(keep, extra)                                              # same result in one pass
+  for k in grown.tensors:
+    assert torch.equal(fused.tensors[k], grown.tensors[k]), k
+  for k in GROUPS:
+    for n in ("exp_avg", "exp_avg_sq"):
+      assert torch.equal(fused.tensor_state[k][n], grown.tensor_state[k][n]), (k, n)
+  assert torch.equal(fused._state["step"], grown._state["step"]) and fused.position.requires_grad
   assert grown.update_groups(position=0.1, feature=dict(lr=1.0))["position"] == 0.1
   restored = optim.ParameterClass.from_state_dict(grown.state_dict(), optimizer=optim.VisibilityAwareLaProp)
   assert torch.equal(restored.position, grown.position) and restored.num_points == grown.num_points

@@ -6,11 +6,13 @@
 //   * the tile's depth-sorted splat list is walked with WAVE-UNIFORM addresses, so the 48-byte record of the
 //     current splat arrives through the scalar data cache into SGPRs (s_load_dwordx4/x8): no VGPRs, no LDS, no
 //     barrier; the next record is prefetched while the current one is evaluated;
-//   * every per-splat reduction over the tile's 256 pixels is 4 in-register adds + one DPP wave reduction
-//     (row_shr / row_bcast) -- i.e. the cross-lane cost is paid once per 256 pixels, not once per 64;
-//   * no float atomics: each (tile, splat) pair owns one slot of a partial buffer, written by lane 63 after
-//     the fixed-order wave reduction and summed per splat in id order afterwards -> bit-reproducible
-//     gradients and densification heuristics;
+//   * every per-splat reduction over the tile's 256 pixels is paid once per 256 pixels, not once per 64: the backward
+//     pass parks its 11 per-pair sums in the wave's LDS block and 44 reader lanes add them up (the VALU is the binding
+//     unit, the LDS pipe is idle otherwise); the forward pass folds the visibility of four pairs with permlane swaps
+//     + DPP row steps;
+//   * no float atomics: each (tile, splat) pair owns one slot of a partial buffer, written after the fixed-order
+//     reduction and summed per splat in id order afterwards -> bit-reproducible gradients and densification
+//     heuristics;
 //   * the forward pass records, per (tile, splat) pair, the visibility partial sum_px T*alpha; a pair whose
 //     partial is zero touched no pixel, so the backward pass skips it without evaluating a single pixel.
 // MFMA is deliberately not used: there is no dense contraction on this path.

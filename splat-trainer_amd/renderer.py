@@ -139,7 +139,7 @@ class _ProjectFn(torch.autograd.Function):
   sync: the size of ``indexes`` is data dependent)."""
 
   @staticmethod
-  def forward(ctx, position, log_scaling, rotation, alpha_logit, T, proj, cull_args, params, grad_out):
+  def forward(ctx, position, log_scaling, rotation, alpha_logit, T, proj, cull_args, params, grad_out, prefetch):
     lib = _lib.load()
     pos, ls, rot, al = _f32c(position), _f32c(log_scaling), _f32c(rotation), _f32c(alpha_logit)
     N, dev = pos.shape[0], pos.device
@@ -158,6 +158,10 @@ class _ProjectFn(torch.autograd.Function):
                                        stream), "gsr_project_forward")
     M = int(count.item())          # host sync #1 (K2 is already running)
     indexes, g2d, depth = indexes_full[:M], g2d_full[:M], depth_full[:M]
+    if prefetch is not None and M > 0:
+      # the caller will rasterize next: the depth sort needs only `depth`, so it is enqueued now and runs while the host
+      # works its way to render_projected (the GPU would otherwise idle behind the sync)
+      prefetch["order"] = _launch_depth_order(depth.reshape(-1), M)
     ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
     ctx.params = params
     ctx.grad_out = grad_out
@@ -185,16 +189,19 @@ class _ProjectFn(torch.autograd.Function):
                                           _ptr(d_ls), _ptr(d_rot), _ptr(d_al), 1 if go is not None else 0,
                                           _stream()), "gsr_project_backward")
     if go is not None:
-      return None, None, None, None, None, None, None, None, None
+      return None, None, None, None, None, None, None, None, None, None
     dt = ctx.in_dtypes
-    return d_pos.to(dt[0]), d_ls.to(dt[1]), d_rot.to(dt[2]), d_al.to(dt[3]), None, None, None, None, None
+    return d_pos.to(dt[0]), d_ls.to(dt[1]), d_rot.to(dt[2]), d_al.to(dt[3]), None, None, None, None, None, None
 
 
 def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
-                     grad_out: Optional[GradOut] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                     grad_out: Optional[GradOut] = None, prefetch: Optional[dict] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
   """K1 cull + K2 projection.  Returns ``gaussians2d (M,6) = [u v A B C opacity]``, ``depth (M,1)``,
   ``indexes (M,) int64`` (ascending).  Differentiable wrt position / log_scaling / rotation /
-  alpha_logit; gradients land in N-sized tensors, zero outside ``indexes``."""
+  alpha_logit; gradients land in N-sized tensors, zero outside ``indexes``.
+  ``prefetch={}``: the depth sort render_projected needs is enqueued right away (it only depends on ``depth``) and handed
+  back as ``prefetch["depth_order"]`` for ``render_projected(..., _depth_order=prefetch["depth_order"])``."""
   _require_device(gaussians.position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit)
   T = _f32c(camera_params.T_camera_world)
   proj = _f32c(camera_params.projection)
@@ -203,7 +210,9 @@ def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config
   cull_args = (int(W), int(H), float(camera_params.near_plane), float(camera_params.far_plane),
                float(config.margin_tiles * config.tile_size))
   g2d, depth, indexes = _ProjectFn.apply(gaussians.position, gaussians.log_scaling, gaussians.rotation,
-                                         gaussians.alpha_logit, T, proj, cull_args, params, grad_out)
+                                         gaussians.alpha_logit, T, proj, cull_args, params, grad_out, prefetch)
+  if prefetch is not None and "order" in prefetch:
+    prefetch["depth_order"] = (prefetch.pop("order"), depth, depth._version)   # pass as render_projected(_depth_order=)
   return g2d, depth, indexes
 
 
@@ -219,8 +228,22 @@ def _u32(n: int, device) -> torch.Tensor:
   return torch.empty(max(n, 1), dtype=torch.int32, device=device)   # raw storage for uint32 arrays
 
 
+def _launch_depth_order(depth: torch.Tensor, M: int) -> torch.Tensor:
+  """depth keys + stable 32-bit radix sort of the M splats (ties keep ascending index); returns order (M,) int32."""
+  lib = _lib.load()
+  dev = depth.device
+  stream = _stream()
+  keys_a, keys_b, vals_a, vals_b = _u32(M, dev), _u32(M, dev), _u32(M, dev), _u32(M, dev)
+  sort_bytes = lib.gsr_sort_workspace_bytes(M)
+  sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
+  _lib.check(lib.gsr_depth_keys(_ptr(depth), M, _ptr(keys_a), stream), "gsr_depth_keys")
+  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, 32,
+                                            _ptr(sort_ws), sort_bytes, stream), "gsr_sort_pairs_u32(depth)")
+  return vals_b if where == 1 else vals_a
+
+
 def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tensor, st: _RasterState,
-                       need_vis_partial: bool) -> torch.Tensor:
+                       need_vis_partial: bool, order: Optional[torch.Tensor] = None) -> torch.Tensor:
   lib = _lib.load()
   dev = g2d.device
   M, C_, W, H = st.M, st.C, st.W, st.H
@@ -245,14 +268,8 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     return blank()
   st.screen_scale = torch.empty(M, 2, dtype=torch.float32, device=dev)   # written for every splat by K4
 
-  # depth order of the M splats (stable: ties keep ascending index)
-  keys_a, keys_b, vals_a, vals_b = _u32(M, dev), _u32(M, dev), _u32(M, dev), _u32(M, dev)
-  sort_bytes = lib.gsr_sort_workspace_bytes(M)
-  sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
-  _lib.check(lib.gsr_depth_keys(_ptr(depth), M, _ptr(keys_a), stream), "gsr_depth_keys")
-  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, 32,
-                                            _ptr(sort_ws), sort_bytes, stream), "gsr_sort_pairs_u32(depth)")
-  st.order = vals_b if where == 1 else vals_a
+  # depth order of the M splats (stable: ties keep ascending index); project_to_image may already have enqueued it
+  st.order = order if order is not None else _launch_depth_order(depth, M)
 
   # per-splat tile counts + depth-ordered records
   st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
@@ -273,6 +290,12 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   if O == 0:
     heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))
     return blank()
+  # emit (tile id, instance) in depth order first: its two output arrays are all it needs, and the GPU has been idle
+  # since the sync -- every other O-sized allocation happens while it runs
+  tkeys_a, trank_a = _u32(O, dev), _u32(O, dev)
+  _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
+                               _ptr(trank_a), stream), "gsr_tile_emit")
+  tkeys_b, tvals_a, tvals_b, trank_b = _u32(O, dev), _u32(O, dev), _u32(O, dev), _u32(O, dev)
   # everything that must start at zero comes out of ONE zero-filled allocation (one fill launch instead of three)
   n_vis = O if need_vis_partial else 0
   zeros = torch.zeros(2 * M + 2 * num_tiles + n_vis, dtype=torch.float32, device=dev)
@@ -284,11 +307,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   st.median = torch.empty(H, W, dtype=torch.float32, device=dev) if st.want_median else None
   st.visibility = (torch.empty if st.compute_visibility else torch.zeros)(M, dtype=torch.float32, device=dev)
 
-  # emit (tile id, instance) in depth order, stable-sort by tile id, find per-tile ranges
-  tkeys_a, tkeys_b, tvals_a, tvals_b = _u32(O, dev), _u32(O, dev), _u32(O, dev), _u32(O, dev)
-  trank_a, trank_b = _u32(O, dev), _u32(O, dev)
-  _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
-                               _ptr(trank_a), stream), "gsr_tile_emit")
+  # stable-sort the pairs by tile id, find per-tile ranges
   tile_bits = max(1, int(math.ceil(math.log2(num_tiles)))) if num_tiles > 1 else 1
   tsort_bytes = lib.gsr_sort_workspace_bytes(O)
   tsort_ws = torch.empty(tsort_bytes, dtype=torch.uint8, device=dev)
@@ -319,9 +338,9 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
 
 class _RasterFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, g2d, feats, depth, st: _RasterState):
+  def forward(ctx, g2d, feats, depth, st: _RasterState, order):
     g, f, d = _f32c(g2d), _f32c(feats), _f32c(depth).reshape(-1)
-    image = _bin_and_composite(g, f, d, st, need_vis_partial=st.compute_visibility or st.needs_grad)
+    image = _bin_and_composite(g, f, d, st, need_vis_partial=st.compute_visibility or st.needs_grad, order=order)
     ctx.st = st
     ctx.in_dtypes = (g2d.dtype, feats.dtype)      # e.g. fp16 colours from an autocast MLP (mlp_scene.py:362)
     return image
@@ -355,12 +374,12 @@ class _RasterFn(torch.autograd.Function):
                                           _ptr(st.order), st.M, st.C, _ptr(d_g2d), _ptr(d_feat),
                                           _ptr(st.prune_cost), _ptr(st.split_score), stream),
                  "gsr_reduce_gradients")
-    return d_g2d.to(ctx.in_dtypes[0]), d_feat.to(ctx.in_dtypes[1]), None, None
+    return d_g2d.to(ctx.in_dtypes[0]), d_feat.to(ctx.in_dtypes[1]), None, None, None
 
 
 def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features: torch.Tensor,
                      depth: torch.Tensor, camera_params: CameraParams, config: RasterConfig,
-                     render_median_depth: bool = False, **_unused) -> Rendering:
+                     render_median_depth: bool = False, _depth_order=None, **_unused) -> Rendering:
   """K4 tile binning -> K5 radix sort -> K6 composite; autograd backward = K7 (+ per-point heuristics).
 
   ``features`` is (M, C) with C in {1, 2, 3}.  ``points.prune_cost`` / ``points.split_score`` of the
@@ -381,7 +400,10 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
   st.vis_partial = None
   st.pair_vis = None
   st.needs_grad = torch.is_grad_enabled() and (gaussians2d.requires_grad or features.requires_grad)
-  image = _RasterFn.apply(gaussians2d, features, depth, st)
+  order = None
+  if _depth_order is not None and _depth_order[1] is depth and _depth_order[2] == depth._version:
+    order = _depth_order[0]                 # enqueued by project_to_image(prefetch=...) for exactly this tensor
+  image = _RasterFn.apply(gaussians2d, features, depth, st, order)
   points = RenderedPoints(idx=indexes, depths=depth, opacity=gaussians2d[:, 5], screen_scale=st.screen_scale,
                           visibility=st.visibility, prune_cost=st.prune_cost, split_score=st.split_score)
   return Rendering(image=image, camera=camera_params, points=points, median_depth_image=st.median,
@@ -395,7 +417,8 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
   ``use_sh``: ``gaussians.feature`` is (N, 3, K) SH coefficients evaluated towards the camera;
   otherwise it is an (N, C) per-point colour."""
   config = config or RasterConfig()
-  g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out)
+  prefetch = {}
+  g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out, prefetch=prefetch)
   if use_sh:
     sh_out = None
     if sh_collector is not None:            # data-parallel: exchange colour-gradient factors, not d_sh (sh.py)
@@ -409,4 +432,4 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
       raise ValueError("grad_out with use_sh=False: gather the features yourself or use plain autograd")
     feats = gaussians.feature[indexes]
   return render_projected(indexes, g2d, feats, depth, camera_params, config,
-                          render_median_depth=render_median_depth, **options)
+                          render_median_depth=render_median_depth, _depth_order=prefetch.get("depth_order"), **options)

@@ -125,3 +125,29 @@ def test_two_rank_sh_factor_exchange_matches_all_reduce():
   res = json.loads(line)
   assert res["n_gpus"] == 2 and res["config"]["cameras_per_step"] == 2
   assert res["config"]["collective_check_rel_err"] < 1e-5
+
+
+def test_prefetched_depth_order_is_used_only_for_the_tensor_it_was_made_for():
+  """project_to_image(prefetch=d) enqueues the depth sort early; render_projected must take it only when it is handed
+  the very same, unmodified depth tensor -- otherwise it sorts again (a stale order would composite in the wrong order)."""
+  g, cam = small_scene(n=1500, w=96, h=64, sh_degree=0, seed=11)
+  dev = "cuda"
+  g, cam = g.to(dev), cam.to(dev)
+  cfg = sta.RasterConfig()
+  with torch.no_grad():
+    d = {}
+    g2d, depth, idx = sta.project_to_image(g, cam, cfg, prefetch=d)
+    assert "depth_order" in d and d["depth_order"][1] is depth
+    feats = torch.rand(idx.shape[0], 3, device=dev)
+    ref = sta.render_projected(idx, g2d, feats, depth, cam, cfg).image                       # no prefetch: sorts itself
+    same = sta.render_projected(idx, g2d, feats, depth, cam, cfg, _depth_order=d["depth_order"]).image
+    assert torch.equal(same, ref)
+    # a different depth tensor (reversed order of the splats in depth) with the stale prefetch handed in
+    flipped = (depth.max() + depth.min() - depth).contiguous()
+    want = sta.render_projected(idx, g2d, feats, flipped, cam, cfg).image
+    got = sta.render_projected(idx, g2d, feats, flipped, cam, cfg, _depth_order=d["depth_order"]).image
+    assert torch.equal(got, want) and not torch.equal(want, ref)
+    # the same tensor modified in place after the prefetch: version counter differs -> ignored as well
+    depth.copy_(flipped)
+    got2 = sta.render_projected(idx, g2d, feats, depth, cam, cfg, _depth_order=d["depth_order"]).image
+    assert torch.equal(got2, want)

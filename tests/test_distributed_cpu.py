@@ -86,6 +86,14 @@ def test_grad_bucket_layout():
   assert ps[0].grad.data_ptr() == b.views[0].data_ptr()      # autograd accumulated in place
   b.zero()
   assert b.flat.abs().sum() == 0 and b.extra.shape == (7,)
+  # zero(except_views): the named slots keep their contents (the SH backward overwrites them), everything else is cleared
+  b.flat.fill_(3.0)
+  b.zero(except_views=(2,))
+  assert torch.all(b.views[2] == 3) and torch.all(b.views[0] == 0) and torch.all(b.views[1] == 0) and torch.all(b.extra == 0)
+  b.flat.fill_(3.0)
+  b.zero(except_views=(0, 1))
+  assert torch.all(b.views[0] == 3) and torch.all(b.views[1] == 3) and torch.all(b.views[2] == 0) and torch.all(b.extra == 0)
+  assert b.all_reduce() is None and b.all_reduce(async_op=True) is None          # no process group: nothing to do
 
 
 def _factor_worker(rank, world, port, out_path):

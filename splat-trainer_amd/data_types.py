@@ -105,6 +105,14 @@ class Gaussians3D:
   def to(self, device=None, dtype=None) -> "Gaussians3D":
     return Gaussians3D(**{f.name: getattr(self, f.name).to(device=device, dtype=dtype) for f in fields(self)})
 
+  def to_tensordict(self) -> dict:
+    """Plain dict of the row tensors (tensordict is not available here; scripts/test_split.py:33, mlp_scene.py:73)."""
+    return {f.name: getattr(self, f.name) for f in fields(self)}
+
+  @classmethod
+  def from_tensordict(cls, d) -> "Gaussians3D":
+    return cls(**{f.name: d[f.name] for f in fields(cls)})
+
   def requires_grad_(self, flag: bool = True) -> "Gaussians3D":
     for f in fields(self):
       getattr(self, f.name).requires_grad_(flag)

@@ -112,3 +112,38 @@ def test_point_state_consumes_rendered_points():
     st.add_rendering(sta.Rendering(image=torch.zeros(2, 2, 3), camera=None, points=pts))
   split, prune = find_split_prune_indexes(st, t=0.2, target_points=60, min_views=1)
   assert split.dtype == torch.bool and not (split & prune).any() and split.sum() > 0
+
+
+def test_compat_names_of_the_import_swap():
+  """TaichiQueue / count_nonfinite / random test data exist with the call shapes the reference uses
+  (mlp_scene.py:417, trainer.py:582, scripts/test_split.py:21-25)."""
+  import math
+  import torch
+  import splat_trainer_amd as sta
+  sta.TaichiQueue.init(arch=None, debug=True, threaded=True)
+  assert sta.TaichiQueue.run_sync(lambda a, b: a + b, 2, b=3) == 5
+  state = dict(points=dict(position=torch.tensor([[1.0, float("nan")]]), idx=torch.tensor([1, 2])),
+               opt=[torch.tensor([float("inf"), 1.0, -float("inf")])], ok=torch.ones(3))
+  assert sta.count_nonfinite(state, "scene") == {"scene.points.position": 1, "scene.opt[0]": 2}
+  assert sta.count_nonfinite(dict(a=torch.ones(2)), "x") == {}
+  try:
+    sta.check_finite(state, "scene")
+    raise AssertionError("check_finite did not raise")
+  except ValueError:
+    pass
+  gen = torch.Generator().manual_seed(0)
+  cam = sta.random_camera(image_size=(640, 480), generator=gen)
+  g = sta.random_3d_gaussians(50, cam, alpha_range=(0.5, 1.0), scale_factor=0.2, generator=gen)
+  assert cam.image_size == (640, 480) and g.position.shape == (50, 3) and g.feature.shape == (50, 3)
+  op = torch.sigmoid(g.alpha_logit)
+  assert float(op.min()) >= 0.5 - 1e-6 and float(op.max()) <= 1.0
+  # every generated point projects inside the image, in front of the camera
+  p = (cam.T_camera_world @ torch.cat([g.position, torch.ones(50, 1)], dim=1).T).T
+  u = p[:, 0] / p[:, 2] * cam.projection[0] + cam.projection[2]
+  v = p[:, 1] / p[:, 2] * cam.projection[1] + cam.projection[3]
+  assert bool((p[:, 2] > 0).all()) and bool(((u >= -1e-3) & (u <= 640 + 1e-3) & (v >= -1e-3) & (v <= 480 + 1e-3)).all())
+  R = cam.T_camera_world[:3, :3]
+  assert torch.allclose(R @ R.T, torch.eye(3), atol=1e-5) and math.isclose(float(torch.linalg.det(R)), 1.0, abs_tol=1e-5)
+  d = g.to_tensordict()
+  assert set(d) == {"position", "rotation", "log_scaling", "alpha_logit", "feature"}
+  assert sta.Gaussians3D.from_tensordict(d).position is g.position

@@ -151,3 +151,25 @@ def test_prefetched_depth_order_is_used_only_for_the_tensor_it_was_made_for():
     depth.copy_(flipped)
     got2 = sta.render_projected(idx, g2d, feats, depth, cam, cfg, _depth_order=d["depth_order"]).image
     assert torch.equal(got2, want)
+
+
+def test_test_split_script_flow():
+  """splat_trainer/scripts/test_split.py:21-38 with this build's imports: random camera + 5 random Gaussians -> render;
+  split every Gaussian in two (split.py:87-113) -> render again.  The split keeps the picture close to the original."""
+  from splat_trainer_amd.harness import split_gaussians_uniform
+  sta.TaichiQueue.init(arch=None, debug=True)
+  gen = torch.Generator().manual_seed(5)
+  camera = sta.random_camera(image_size=(640, 480), generator=gen)
+  gaussians = sta.random_3d_gaussians(5, camera, alpha_range=(0.5, 1.0), scale_factor=0.2, generator=gen)
+  device = torch.device("cuda:0")
+  camera, gaussians = camera.to(device), gaussians.to(device)
+  with torch.no_grad():
+    image = sta.render_gaussians(gaussians, camera_params=camera).image
+    assert image.shape == (480, 640, 3) and torch.isfinite(image).all() and float(image.max()) > 0.05
+    split = split_gaussians_uniform(gaussians.to_tensordict(), k=2, random_axis=False)
+    image2 = sta.render_gaussians(sta.Gaussians3D.from_tensordict(split), camera_params=camera).image
+  assert split["position"].shape[0] == 10
+  covered = (image.sum(-1) > 0.02)
+  covered2 = (image2.sum(-1) > 0.02)
+  inter = (covered & covered2).sum().item(); union = (covered | covered2).sum().item()
+  assert inter / union > 0.7                                    # same footprint, two smaller blobs per parent

@@ -173,3 +173,50 @@ def test_test_split_script_flow():
   covered2 = (image2.sum(-1) > 0.02)
   inter = (covered & covered2).sum().item(); union = (covered | covered2).sum().item()
   assert inter / union > 0.7                                    # same footprint, two smaller blobs per parent
+
+
+def test_transfer_sh_flow():
+  """splat_trainer/scene/transfer_sh.py:17-113 with this build's ``evaluate_sh_at``: per-point SH coefficients are
+  fitted (Adam, base lr 0.1, higher orders lr/10 + weight decay) to view-dependent colours of the visible points of
+  each camera, visibility-weighted MSE + 0.1 L1 on the base colour.  The fit must converge."""
+  from splat_trainer_amd import synthetic
+  dev = "cuda"
+  g, cams = synthetic.scene_b(4000, 160, 120, sh_degree=2, seed=9, num_cameras=8)
+  g = g.to(dev)
+  cams = [c.to(dev) for c in cams]
+  cfg = sta.RasterConfig(compute_visibility=True)
+  positions = g.position
+  true_sh = g.feature * 0.5                                                    # the "colour model" to be transferred
+
+  def query_visibility(cam):                                                   # mlp_scene: render with visibility
+    with torch.no_grad():
+      r = sta.render_gaussians(g, cam, cfg, use_sh=True)
+    vis = r.points.visibility > 0
+    return r.points.idx[vis], r.points.visibility[vis]
+
+  def eval_colors(idx, cam):
+    with torch.no_grad():
+      return sta.evaluate_sh_at(true_sh, positions, idx, cam.camera_position).clamp(0, 1)
+
+  n = positions.shape[0]
+  base_sh = torch.nn.Parameter(torch.randn(n, 3, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(0)))
+  higher_sh = torch.nn.Parameter(torch.zeros(n, 3, 8, device=dev))
+  opt = torch.optim.Adam([dict(params=[base_sh], lr=0.1), dict(params=[higher_sh], lr=0.01, weight_decay=1e-4)],
+                         betas=(0.9, 0.999))
+  sh0 = 0.282094791773878
+  losses = []
+  for epoch in range(6):
+    for cam in cams:
+      opt.zero_grad()
+      idx, vis = query_visibility(cam)
+      colors = eval_colors(idx, cam)
+      with torch.enable_grad():
+        pred = sta.evaluate_sh_at(torch.cat([base_sh, higher_sh], dim=2), positions, idx, cam.camera_position).clamp(0, 1)
+        mse = torch.nn.functional.mse_loss(pred, colors, reduction="none")
+        rgb = torch.nn.functional.l1_loss((base_sh.squeeze(2) * sh0 + 0.5)[idx], colors)
+        v = vis.unsqueeze(1)
+        loss = (mse * v).sum() / v.sum() + 0.1 * rgb
+        loss.backward()
+      opt.step()
+      losses.append(float(loss.detach()))
+  assert losses[-1] < 0.1 * losses[0] and all(torch.isfinite(p).all() for p in (base_sh, higher_sh))

@@ -203,6 +203,48 @@ def test_full_size_properties_config2(n, w, h):
     assert (img[ys, xs] - out.image[ys, xs]).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("n,w,h,deg", [(3_000_000, 1920, 1080, 3), (10_000_000, 3840, 2160, 1)])
+def test_full_size_properties_large_configs(n, w, h, deg):
+  """BASELINE.json configs[2] / configs[4] sizes (3M at 1080p; 10M at 4K with the frustum cull active), one camera.
+  Properties that need no oracle:
+     (1) unit features: image + final_T == 1 at every pixel;
+     (2) d(sum image)/d feature == visibility;
+     (3) the backward pass is linear in dL/dimage, and scaling by a power of two is exact in fp32: every gradient and
+         heuristic of the run with 4 x dL/dimage is bit-for-bit 4 x the first run's;
+     (4) indexes ascending, inside [0, N), depths within [near, far]."""
+  g, cams = synthetic.scene_b(n, w, h, sh_degree=deg, seed=1, num_cameras=8)
+  cam = cams[0].to("cuda")
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  leaves = [t.cuda().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+  scene = sta.Gaussians3D(position=leaves[0], log_scaling=leaves[1], rotation=leaves[2], alpha_logit=leaves[3],
+                          feature=leaves[4])
+  with torch.no_grad():
+    g2d, depth, idx = sta.project_to_image(scene, cam, cfg)
+    m = idx.numel()
+    assert 0 < m <= n and bool((idx[1:] > idx[:-1]).all()) and int(idx[-1]) < n
+    assert float(depth.min()) >= cam.near_plane and float(depth.max()) <= cam.far_plane
+  ones = torch.ones(m, 1, device="cuda", requires_grad=True)
+  r = sta.render_projected(idx, g2d, ones, depth, cam, cfg)
+  assert (r.image[..., 0] + r.final_transmittance - 1).abs().max().item() < 5e-5
+  r.image.sum().backward()
+  assert rel_err(ones.grad[:, 0], r.points.visibility) < 5e-5
+  del r, ones
+
+  def run(scale):
+    for t in leaves:
+      t.grad = None
+    with torch.enable_grad():
+      out = sta.render_gaussians(scene, cam, cfg, use_sh=True)
+      weight = torch.linspace(-1, 1, w, device="cuda")[None, :, None].expand(h, w, 3)   # a non-trivial dL/dimage
+      (out.image * weight).sum().mul(scale).backward()
+    return [t.grad.clone() for t in leaves] + [out.points.prune_cost.clone(), out.points.split_score.clone()]
+
+  a, b = run(1.0), run(4.0)
+  for x, y in zip(a, b):
+    assert torch.equal(x * 4, y)
+  assert all(torch.isfinite(x).all() for x in a)
+
+
 def test_grad_out_fused_accumulation_equals_autograd():
   """renderer.GradOut: backward kernels add straight into caller buffers (the parameters' .grad over the
   cameras of a batch, trainer.py:500-514).  Must equal plain autograd accumulation, bit for bit per camera sum,

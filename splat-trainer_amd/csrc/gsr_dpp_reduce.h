@@ -1,322 +1,27 @@
-// GENERATED by the snippet in DESIGN.md (section "DPP reductions"); do not edit by hand.
-// In-place fused wave64 sums: v_add_f32_dpp vN, vN, vN  <ctrl>  -- one VALU op per value per step (the
-// __builtin_amdgcn_update_dpp form compiles to v_mov_b32_dpp + v_add_f32, two ops).  A lane whose DPP source is
-// out of range, or whose row is masked off, is simply not written and keeps its own partial sum, which is the
-// "+ 0" the tree needs.  The N chains are interleaved, so every dependent pair is >= 3 instructions apart and
-// the DPP read-after-VALU-write hazard (2 wait states) is satisfied without s_nop; the leading s_nop covers the
-// producer of the inputs.  Fixed association order => bit-reproducible.  Totals land in lane 63.
+// Fused in-place wave64 cross-lane sums used by the composite forward pass (visibility of four pairs at once):
+//   gsr_swap32_add / gsr_swap16_add   v_permlane{32,16}_swap + add: two registers fold into one, each half (quarter) of
+//                                     the lanes ends up holding the partial sum of one of the two values
+//   gsr_row_sum_to_lane15             v_add_f32_dpp vN, vN, vN row_shr:1/2/4/8 -- one VALU op per step (the
+//                                     __builtin_amdgcn_update_dpp form compiles to v_mov_b32_dpp + v_add_f32, two ops);
+//                                     a lane whose DPP source is out of range is not written and keeps its own partial
+//                                     sum, which is the "+ 0" the tree needs; s_nop covers the DPP read-after-VALU-write
+//                                     hazard.  Totals land in lane 15 of every row.
+// Fixed association order => bit-reproducible.  (The backward pass reduces through LDS instead, see composite.hip; its
+// former register-only 12-value transposing tree was removed with it.)
 #pragma once
 
-__device__ __forceinline__ void gsr_wave_sum3_to_lane63(float& a0, float& a1, float& a2) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      : "+v"(a0), "+v"(a1), "+v"(a2));
-}
-
-__device__ __forceinline__ void gsr_wave_sum8_to_lane63(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float& a6, float& a7) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
-}
-
-__device__ __forceinline__ void gsr_wave_sum9_to_lane63(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float& a6, float& a7, float& a8) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
-}
-
-__device__ __forceinline__ void gsr_wave_sum10_to_lane63(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float& a6, float& a7, float& a8, float& a9) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9));
-}
-
-__device__ __forceinline__ void gsr_wave_sum11_to_lane63(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float& a6, float& a7, float& a8, float& a9, float& a10) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %10, %10, %10 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %10, %10, %10 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %10, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %10, %10, %10 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %10, %10, %10 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %8, %8, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %9, %9, %9 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %10, %10, %10 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10));
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// 12 values at once, transposing as it reduces (gfx950 v_permlane32_swap / v_permlane16_swap):
-//   level 1: swap32(v[2i], v[2i+1]) + add  -> 6 registers, lanes 0-31 hold v[2i] partials, lanes 32-63 v[2i+1]
-//   level 2: swap16(s[2j], s[2j+1]) + add  -> 3 registers, DPP row r of t[j] holds value 4j + {0,2,1,3}[r]
-//   rows   : row_shr 1,2,4,8 (fused DPP)    -> lane 16r+15 of t[j] holds the wave total of that value
-// 9 swap(+add) pairs + 12 DPP adds instead of 72 DPP adds; fixed association order => bit-reproducible.
 __device__ __forceinline__ float gsr_swap32_add(float a, float b) {
   typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
   v2u_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
+
 __device__ __forceinline__ float gsr_swap16_add(float a, float b) {
   typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
   v2u_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-__device__ __forceinline__ void gsr_row_sum3_to_lane15(float& a0, float& a1, float& a2) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n"
-      : "+v"(a0), "+v"(a1), "+v"(a2));
-}
-// single chain: sum of the 16 lanes of each DPP row, total in lane 15 of the row (s_nop covers the DPP hazard)
+
 __device__ __forceinline__ float gsr_row_sum_to_lane15(float a) {
   asm volatile(
       "s_nop 1\n"
@@ -329,14 +34,4 @@ __device__ __forceinline__ float gsr_row_sum_to_lane15(float a) {
       "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
       : "+v"(a));
   return a;
-}
-// v[0..11] -> t0, t1, t2 ; lane 16r+15 of tj holds the total of v[4j + {0,2,1,3}[r]]
-__device__ __forceinline__ void gsr_wave_sum12_transposed(const float (&v)[12], float& t0, float& t1, float& t2) {
-  const float s0 = gsr_swap32_add(v[0], v[1]), s1 = gsr_swap32_add(v[2], v[3]);
-  const float s2 = gsr_swap32_add(v[4], v[5]), s3 = gsr_swap32_add(v[6], v[7]);
-  const float s4 = gsr_swap32_add(v[8], v[9]), s5 = gsr_swap32_add(v[10], v[11]);
-  t0 = gsr_swap16_add(s0, s1);
-  t1 = gsr_swap16_add(s2, s3);
-  t2 = gsr_swap16_add(s4, s5);
-  gsr_row_sum3_to_lane15(t0, t1, t2);
 }

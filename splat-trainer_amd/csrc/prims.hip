@@ -75,37 +75,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
   if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = boff + total;
 }
 
-// One-launch scan for small inputs (the radix-sort digit tables): a single 1024-thread block, every thread owns
-// a contiguous run of ceil(n/1024) entries (read twice: sum, then prefix), one block-wide scan in between.
-// in may alias out.
-constexpr int SMALL_SCAN_MAX = 65536;
-__global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* in, uint32_t n, uint32_t* out,
-                                                          uint32_t* __restrict__ total_out) {
-  __shared__ uint32_t s_wave[16];
-  const int lane = gsr_lane(), wave = threadIdx.x >> 6;
-  const uint32_t per = (n + 1023u) >> 10;
-  const uint32_t i0 = threadIdx.x * per;
-  const uint32_t i1 = min(i0 + per, n);
-  uint32_t sum = 0;
-  for (uint32_t i = i0; i < i1; ++i) sum += in[i];
-  const uint32_t incl = gsr_wave_scan_incl_u32(sum);
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  uint32_t wbase = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    const uint32_t c = s_wave[w];
-    if (w < wave) wbase += c;
-    total += c;
-  }
-  uint32_t run = wbase + incl - sum;
-  for (uint32_t i = i0; i < i1; ++i) {
-    const uint32_t v = in[i];
-    out[i] = run;
-    run += v;
-  }
-  if (total_out && threadIdx.x == 0) *total_out = total;
-}
 
 size_t scan_ws_bytes(uint64_t n) {
   size_t bytes = 0;
@@ -125,11 +94,6 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
   uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
   if (nb == 1) {
     scan_apply_kernel<<<1, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, nullptr, out, total_dev);
-    GSR_CHECK_LAUNCH();
-    return GSR_OK;
-  }
-  if (false && n <= SMALL_SCAN_MAX) {   // measured slower than the 3-launch form on MI355X (latency-bound single block)
-    scan_small_kernel<<<1, 1024, 0, stream>>>(in, (uint32_t)n, out, total_dev);
     GSR_CHECK_LAUNCH();
     return GSR_OK;
   }

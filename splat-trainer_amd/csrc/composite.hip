@@ -347,8 +347,10 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
         float* wr = red + wslot;
         wr[0 * 80] = du; wr[1 * 80] = dv; wr[2 * 80] = dA; wr[3 * 80] = dB; wr[4 * 80] = dC; wr[5 * 80] = dop;
         wr[6 * 80] = prune; wr[7 * 80] = split; wr[8 * 80] = df[0]; wr[9 * 80] = df[1]; wr[10 * 80] = df[2];
+        gsr_wave_lds_fence();                                  // parks above are visible to the reader lanes below
         const float4* rd = reinterpret_cast<const float4*>(red + rslot);
         const float4 a = rd[0], b = rd[1], c = rd[2], d = rd[3];
+        gsr_wave_lds_fence();                                  // reads done before the next pair parks into the same cells
         const v2f t = (((v2f){a.x, a.y} + (v2f){a.z, a.w}) + ((v2f){b.x, b.y} + (v2f){b.z, b.w})) +
                       (((v2f){c.x, c.y} + (v2f){c.z, c.w}) + ((v2f){d.x, d.y} + (v2f){d.z, d.w}));
         float tot = t.x + t.y;

@@ -20,6 +20,15 @@
     if (e__ != hipSuccess) return GSR_ERR_LAUNCH_FAILED;     \
   } while (0)
 
+// Orders this wave's LDS accesses across its lanes (one wave per workgroup exchanges data through LDS without
+// s_barrier): a wavefront-scope fence + wave barrier.  Emits no instruction -- LDS operations of one wave execute in
+// order -- but keeps the compiler from moving the reads above the writes (or the next writes above the reads).
+__device__ __forceinline__ void gsr_wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int gsr_lane() { return (int)(threadIdx.x & 63); }
 
 // v + (DPP-moved v); lanes without a source read 0 (bound_ctrl).

@@ -13,6 +13,8 @@ from typing import Any, Optional, Tuple
 
 import torch
 
+from .tensor_rows import TensorRows
+
 
 @dataclass(frozen=True)
 class RasterConfig:
@@ -85,14 +87,25 @@ class CameraParams:
     return self.projection[2:4]
 
 
-@dataclass
 class Gaussians3D:
-  """mlp_scene.py:401-407.  rotation is a quaternion in **xyzw** order (scene/io.py:102-104)."""
-  position: torch.Tensor      # (N, 3)
-  rotation: torch.Tensor      # (N, 4) xyzw
-  log_scaling: torch.Tensor   # (N, 3)
-  alpha_logit: torch.Tensor   # (N, 1)
-  feature: torch.Tensor       # (N, F) or (N, 3, K) SH coefficients
+  """mlp_scene.py:401-407.  rotation is a quaternion in **xyzw** order (scene/io.py:102-104).
+
+  Accepts the calls the reference makes on the upstream tensorclass: keyword construction with an (ignored, checked)
+  ``batch_size=`` (scene/io.py:106-115), ``Gaussians3D.from_dict(td, batch_dims=1)`` (mlp_scene.py:398),
+  ``gaussians.apply(torch.detach)`` (scene/io.py:122), ``to_tensordict`` / ``from_tensordict``
+  (scripts/test_split.py:33-34)."""
+  FIELDS = ("position", "rotation", "log_scaling", "alpha_logit", "feature")
+  __slots__ = FIELDS
+
+  def __init__(self, position: torch.Tensor, rotation: torch.Tensor, log_scaling: torch.Tensor,
+               alpha_logit: torch.Tensor, feature: torch.Tensor, batch_size=None):
+    self.position = position        # (N, 3)
+    self.rotation = rotation        # (N, 4) xyzw
+    self.log_scaling = log_scaling  # (N, 3)
+    self.alpha_logit = alpha_logit  # (N, 1)
+    self.feature = feature          # (N, F) or (N, 3, K) SH coefficients
+    if batch_size is not None and tuple(int(b) for b in batch_size) != (int(position.shape[0]),):
+      raise ValueError(f"batch_size {tuple(batch_size)} does not match {position.shape[0]} points")
 
   @property
   def batch_size(self):
@@ -102,21 +115,38 @@ class Gaussians3D:
   def device(self):
     return self.position.device
 
-  def to(self, device=None, dtype=None) -> "Gaussians3D":
-    return Gaussians3D(**{f.name: getattr(self, f.name).to(device=device, dtype=dtype) for f in fields(self)})
+  def apply(self, fn, batch_size=None) -> "Gaussians3D":
+    """New instance with ``fn`` applied to every field (``gaussians.apply(torch.detach)``, scene/io.py:122)."""
+    return Gaussians3D(**{name: fn(getattr(self, name)) for name in self.FIELDS}, batch_size=batch_size)
 
-  def to_tensordict(self) -> dict:
-    """Plain dict of the row tensors (tensordict is not available here; scripts/test_split.py:33, mlp_scene.py:73)."""
-    return {f.name: getattr(self, f.name) for f in fields(self)}
+  def to(self, device=None, dtype=None) -> "Gaussians3D":
+    return self.apply(lambda t: t.to(device=device, dtype=dtype))
+
+  def detach(self) -> "Gaussians3D":
+    return self.apply(torch.detach)
+
+  def to_dict(self) -> dict:
+    return {name: getattr(self, name) for name in self.FIELDS}
+
+  def to_tensordict(self) -> TensorRows:
+    """Row container of the five tensors (scripts/test_split.py:33, mlp_scene.py:73)."""
+    return TensorRows(self.to_dict())
 
   @classmethod
-  def from_tensordict(cls, d) -> "Gaussians3D":
-    return cls(**{f.name: d[f.name] for f in fields(cls)})
+  def from_dict(cls, d, batch_dims: int = 1) -> "Gaussians3D":
+    if batch_dims != 1:
+      raise ValueError("Gaussians3D has one batch dimension (the points)")
+    return cls(**{name: d[name] for name in cls.FIELDS})
+
+  from_tensordict = from_dict
 
   def requires_grad_(self, flag: bool = True) -> "Gaussians3D":
-    for f in fields(self):
-      getattr(self, f.name).requires_grad_(flag)
+    for name in self.FIELDS:
+      getattr(self, name).requires_grad_(flag)
     return self
+
+  def __repr__(self):
+    return "Gaussians3D(" + ", ".join(f"{n}={tuple(getattr(self, n).shape)}" for n in self.FIELDS) + ")"
 
 
 def _index_rows(value: Any, rows: torch.Tensor) -> Any:

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from .controller_math import PointState, find_split_prune_indexes
 from .data_types import CameraParams, Gaussians3D, RasterConfig
 from .optim import ParameterClass, VisibilityAwareLaProp
+from .tensor_rows import TensorRows
 from .renderer import render_gaussians
 
 PARAM_NAMES = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
@@ -47,25 +48,29 @@ def point_basis(log_scaling: torch.Tensor, rotation: torch.Tensor, eps: float = 
   return quat_to_rotmat_xyzw(rotation) * torch.clamp_min(torch.exp(log_scaling), eps).unsqueeze(-2)
 
 
-def split_gaussians_uniform(points: dict, k: int = 2, sep: float = 0.7, random_axis: bool = True,
-                            eps: float = 1e-4, generator: Optional[torch.Generator] = None) -> dict:
-  """split.py:87-113 over a dict of row tensors."""
+def split_gaussians_uniform(points: TensorRows, k: int = 2, scaling: Optional[float] = None, sep: float = 0.7,
+                            random_axis: bool = False, eps: float = 1e-4,
+                            generator: Optional[torch.Generator] = None) -> TensorRows:
+  """gaussians/split.py:87-113 over a TensorRows: every parent becomes ``k`` children spread over [-sep, sep] sigma
+  along one axis (sampled in proportion to the scales, or the largest), and that axis shrinks by ``scaling`` (default
+  1/sqrt(k)).  The reference shrinks first -- ``points.update(...)`` is in place, so the ``point_basis`` that places the
+  children already sees the shrunk axis -- hence the children sit at +/- sep * scaling * sigma, not +/- sep * sigma.
+  All columns of ``points`` (extras such as ``visible`` included) are repeated k times, as split_with_offsets does."""
+  points = points if isinstance(points, TensorRows) else TensorRows(points)
   ls = points["log_scaling"]
   if random_axis:
-    probs = F.normalize(torch.clamp_min(ls.exp(), eps), dim=1)
-    axis = torch.multinomial(probs, num_samples=1, generator=generator).squeeze(1)
+    weights = F.normalize(torch.clamp_min(ls.exp(), eps), dim=1)
+    pick = torch.multinomial(weights, num_samples=1, generator=generator).squeeze(1)
   else:
-    axis = torch.argmax(ls, dim=1)
-  axis = F.one_hot(axis, num_classes=3).to(ls.dtype)
-  values = torch.linspace(-sep, sep, k, device=ls.device)
-  samples = values.view(1, -1, 1) * axis.view(-1, 1, 3)                  # (n, k, 3) local offsets
-  scaling = 1.0 / math.sqrt(k)
-  basis = point_basis(ls, points["rotation"])                           # unscaled parent basis
-  offsets = (basis.repeat_interleave(k, dim=0) @ samples.reshape(-1, 3, 1)).reshape(-1, 3)
-  out = {name: t.repeat_interleave(k, dim=0) for name, t in points.items()}
-  out["log_scaling"] = (ls + math.log(scaling) * axis).repeat_interleave(k, dim=0)
-  out["position"] = out["position"] + offsets
-  return out
+    pick = torch.argmax(ls, dim=1)
+  axis = F.one_hot(pick, num_classes=3).to(ls.dtype)                              # (n, 3)
+  scaling = 1.0 / math.sqrt(k) if scaling is None else scaling
+  shrunk = ls + math.log(scaling) * axis
+  steps = torch.linspace(-sep, sep, k, device=ls.device, dtype=ls.dtype)          # (k,)
+  local = steps.view(1, k, 1) * axis.view(-1, 1, 3)                               # (n, k, 3) in splat space
+  offsets = torch.einsum("nij,nkj->nki", point_basis(shrunk, points["rotation"], eps), local)
+  children = points.replace(log_scaling=shrunk).apply(lambda t: t.repeat_interleave(k, dim=0))
+  return children.update(position=children["position"] + offsets.reshape(-1, 3))
 
 
 @dataclass
@@ -159,9 +164,7 @@ class MiniTrainer:
     keep_mask = ~(split_mask | prune_mask)
     split_idx = split_mask.nonzero().squeeze(1)
     # mlp_scene.py:301-310: children from the split rows, kept rows (with their optimizer state), children appended
-    rows = {n: t_.detach()[split_idx] for n, t_ in self.points.tensors.items()}
-    splits = split_gaussians_uniform({n: rows[n] for n in PARAM_NAMES}, k=2, random_axis=True, generator=self.gen)
-    splits["visible"] = rows["visible"].repeat_interleave(2, dim=0)
+    splits = split_gaussians_uniform(self.points[split_idx].detach(), k=2, random_axis=True, generator=self.gen)
     self.points = self.points.keep_and_append(keep_mask, splits)
     self.state = PointState.new_zeros(self.num_points, self.device)   # target_controller.py:120-122
 

@@ -7,7 +7,8 @@ Host-side mirror of the ``taichi_splatting.optim`` names the reference uses -- `
 The arithmetic is specified in ``oracle/optim_oracle.py`` (published Adam / LaProp; the visibility weighting is this
 build's own definition: the reference's lives in a package that is not in its tree -- parity unpinned).
 
-tensordict is not available here: ``tensors`` is a plain ``dict`` of (N, ...) tensors.  Entries named in
+tensordict is not available here: ``tensors`` is a ``TensorRows`` (tensor_rows.py: a dict of (N, ...) tensors with the
+``select`` / ``replace`` / ``to_dict`` / ``apply`` calls the reference makes on it, mlp_scene.py:296,395-396).  Entries named in
 ``parameter_groups`` are optimised; the others (e.g. ``visible``, mlp_scene.py:75) only ride along through indexing
 and appending.  There is no CPU fallback: ``step`` needs the HIP library and CUDA tensors.
 """
@@ -20,6 +21,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
+from .tensor_rows import TensorRows
 
 SCALAR, VECTOR, LOCAL_VECTOR = "scalar", "vector", "local_vector"
 _TYPE_ID = {SCALAR: 0, VECTOR: 1, LOCAL_VECTOR: 2}
@@ -75,10 +77,11 @@ class ParameterClass:
     for k, grp in self.parameter_groups.items():
       if grp["type"] not in _TYPE_ID:
         raise ValueError(f"group {k}: unknown type {grp['type']!r}")
-    self.tensors: Dict[str, torch.Tensor] = {}
+    cols = {}
     for k, t in tensors.items():
       t = t.detach().contiguous()
-      self.tensors[k] = t.requires_grad_(True) if k in self.parameter_groups else t
+      cols[k] = t.requires_grad_(True) if k in self.parameter_groups else t
+    self.tensors = TensorRows(cols)
     self._state = state if state is not None else self._new_state(self.num_points)
 
   # ---------------------------------------------------------------------------------------------------- basics
@@ -96,6 +99,11 @@ class ParameterClass:
 
   def keys(self):
     return self.tensors.keys()
+
+  def detach(self) -> TensorRows:
+    """The rows as a plain container of detached tensors, optimizer state left behind
+    (``self.points[split_idx].detach()``, mlp_scene.py:303)."""
+    return self.tensors.detach()
 
   def __getattr__(self, name):
     tensors = self.__dict__.get("tensors")

@@ -7,7 +7,7 @@ import torch
 
 import splat_trainer_amd as sta
 from splat_trainer_amd import synthetic
-from splat_trainer_amd.harness import MiniTrainer, split_gaussians_uniform
+from splat_trainer_amd.harness import MiniTrainer
 
 pytestmark = pytest.mark.gpu
 
@@ -46,23 +46,6 @@ def test_train_loop_with_densify_prune_is_reproducible():
   assert log2.losses == log.losses and log2.num_points == log.num_points
   for n in tr.params:
     assert torch.equal(tr.params[n], tr2.params[n]), n
-
-
-def test_split_gaussians_uniform_matches_reference_rule():
-  """split.py:87-113: two children at -/+0.7 sigma along one axis, that axis shrunk by 1/sqrt(2)."""
-  torch.manual_seed(0)
-  pts = dict(position=torch.randn(50, 3), log_scaling=torch.randn(50, 3) * 0.3, rotation=torch.randn(50, 4),
-             alpha_logit=torch.randn(50, 1), feature=torch.randn(50, 3, 4))
-  out = split_gaussians_uniform(pts, k=2, random_axis=False)
-  assert out["position"].shape == (100, 3) and out["feature"].shape == (100, 3, 4)
-  axis = torch.argmax(pts["log_scaling"], dim=1)
-  d = (out["position"][0::2] - out["position"][1::2]).norm(dim=1)
-  sigma = pts["log_scaling"].exp().gather(1, axis[:, None]).squeeze(1)
-  assert torch.allclose(d, 1.4 * sigma, rtol=1e-4)
-  mid = 0.5 * (out["position"][0::2] + out["position"][1::2])
-  assert torch.allclose(mid, pts["position"], atol=1e-5)
-  shrunk = out["log_scaling"][0::2].gather(1, axis[:, None]).squeeze(1)
-  assert torch.allclose(shrunk, pts["log_scaling"].gather(1, axis[:, None]).squeeze(1) - 0.5 * torch.log(torch.tensor(2.0)))
 
 
 def test_config_c4_scaled_100_iterations():

@@ -55,7 +55,22 @@ typedef struct GsrRasterParamsC {
 } GsrRasterParamsC;
 #endif
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 10) */
+/* Heavy-tile list segmentation (optional; pass NULL where a GsrSegmentsC* is taken to composite every tile with one
+ * wave).  All pointers are device buffers owned by the caller; tile_seg / seg_desc / seg_total are filled by
+ * gsr_segment_plan, the seg_* pixel buffers are scratch written by the forward pass and read by the backward pass. */
+typedef struct GsrSegmentsC {
+  const uint32_t* tile_seg;   /* [num_tiles,2]: first segment, number of segments (0 = light tile) */
+  const uint32_t* seg_desc;   /* [capacity,4]: tile, list start, list end, index within the tile */
+  const uint32_t* seg_total;  /* device word: segments of this frame (<= capacity) */
+  int64_t capacity;           /* from gsr_segment_capacity */
+  float* seg_P;               /* [capacity,256] */
+  float* seg_T;               /* [capacity,256] */
+  float* seg_C;               /* [capacity,C,256] */
+  int32_t* seg_last;          /* [capacity,256] */
+  float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
+} GsrSegmentsC;
+
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 11) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -146,6 +161,16 @@ int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t 
  * [num_tiles, 2] uint32. */
 int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range, void* stream);
 
+/* ---- heavy-tile list segmentation ----------------------------------------------------------------------- */
+/* One wave walks one tile's depth-sorted list serially; a tile with more than heavy_min (>= seg_pairs) pairs is cut
+ * into ceil(len / seg_pairs) segments that are composited and back-propagated by one wave each.
+ * gsr_segment_capacity: host-side bound on the number of segments of a frame with O overlaps (sizes the buffers). */
+int64_t gsr_segment_capacity(int64_t O, int32_t seg_pairs, int32_t heavy_min);
+/* tile_seg_out [num_tiles,2], seg_desc_out [capacity,4], seg_total_out [1] (see GsrSegmentsC). */
+int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs, int32_t heavy_min,
+                     int64_t capacity, uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out,
+                     void* stream);
+
 /* ---- K6 alpha-composite forward ------------------------------------------------------------------------- */
 /* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;
  * median_depth [H,W] or NULL; vis_partial [O] (indexed by instance id; must be zero-filled) and pair_vis [O]
@@ -154,14 +179,15 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
                           const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                           const GsrRasterParamsC* params_host, float* image_out, float* final_T_out,
                           int32_t* last_out, float* median_depth_out, float* vis_partial_out, float* pair_vis_out,
-                          void* stream);
+                          const GsrSegmentsC* segments_host /* or NULL */, void* stream);
 
 /* ---- K7 alpha-composite backward (per-pixel reverse walk) ----------------------------------------------- */
 /* partial_out [O,12]: written only for pairs with pair_vis > 0 (the others are never read). */
 int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
                            const float* pair_vis, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                            const GsrRasterParamsC* params_host, const float* final_T, const int32_t* last,
-                           const float* dL_dimage, float* partial_out, void* stream);
+                           const float* dL_dimage, float* partial_out,
+                           const GsrSegmentsC* segments_host /* the forward pass's, or NULL */, void* stream);
 
 /* ---- deterministic per-splat reductions of the per-(tile,splat) partials -------------------------------- */
 /* visibility_out [M] indexed by splat (not rank). */

@@ -11,13 +11,19 @@ import threading
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GsrRasterParamsC(C.Structure):
   _fields_ = [("alpha_threshold", C.c_float), ("clamp_max_alpha", C.c_float), ("T_eps", C.c_float),
               ("q_max", C.c_float), ("blur", C.c_float), ("antialias", C.c_int32), ("tile_size", C.c_int32),
               ("margin_px", C.c_float)]
+
+
+class GsrSegmentsC(C.Structure):
+  _fields_ = [("tile_seg", C.c_void_p), ("seg_desc", C.c_void_p), ("seg_total", C.c_void_p), ("capacity", C.c_int64),
+              ("seg_P", C.c_void_p), ("seg_T", C.c_void_p), ("seg_C", C.c_void_p), ("seg_last", C.c_void_p),
+              ("seg_median", C.c_void_p)]
 
 
 def raster_params(config) -> GsrRasterParamsC:
@@ -31,6 +37,7 @@ def raster_params(config) -> GsrRasterParamsC:
 _p = C.c_void_p
 _i64, _i32, _f, _sz = C.c_int64, C.c_int32, C.c_float, C.c_size_t
 _pp = C.POINTER(GsrRasterParamsC)
+_ps = C.POINTER(GsrSegmentsC)
 
 # name -> (restype, argtypes); every symbol declared in include/gsplat_hip.h
 PROTOTYPES = {
@@ -54,8 +61,10 @@ PROTOTYPES = {
     "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p]),
     "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),
     "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p]),
-    "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _p]),
-    "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p]),
+    "gsr_segment_capacity": (_i64, [_i64, _i32, _i32]),
+    "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i64, _p, _p, _p, _p]),
+    "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _ps, _p]),
+    "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _ps, _p]),
     "gsr_opt_point_weights": (C.c_int, [_p, _p, _i64, _p, _p, _f, _f, _f, _f, _i32, _p, _p]),
     "gsr_opt_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f, _f, _f, _f, _f, _p]),
     "gsr_ssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),

@@ -15,6 +15,15 @@
 //     heuristics;
 //   * the forward pass records, per (tile, splat) pair, the visibility partial sum_px T*alpha; a pair whose
 //     partial is zero touched no pixel, so the backward pass skips it without evaluating a single pixel.
+// Heavy tiles (list segmentation): one wave walks one tile's list serially, so a tile with thousands of pairs
+//   would bound both kernels from below (clustered scenes).  gsr_segment_plan cuts the list of every tile longer than
+//   `heavy_min` pairs into segments of <= `seg_pairs` pairs; such a tile is composited by
+//     A) one wave per segment: per-pixel product of (1 - alpha) over the segment (extra blocks of the K6 launch),
+//     C) one wave per segment: the ordinary forward walk, started from T_in = product of the preceding segments,
+//     D) one wave per tile: colours summed in segment order, final T / last / median combined, and the colour BEHIND
+//        each segment left in place of its own colour,
+//   and back-propagated by one wave per segment (extra blocks of the K7 launch) that starts its reverse walk from
+//   the segment's own end state (T after the segment, colour behind it).  Everything stays fixed-order: no atomics.
 // MFMA is deliberately not used: there is no dense contraction on this path.
 #include "gsr_device.h"
 #include "gsr_dpp_reduce.h"
@@ -92,6 +101,148 @@ __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const
   return s;
 }
 
+// Device view of the segment tables (all NULL / 0 when the caller does not segment).
+struct SegDev {
+  const uint32_t* tile_seg;    // [num_tiles, 2]: first segment, number of segments (0: light tile)
+  const uint32_t* seg_desc;    // [capacity, 4]: tile, list start, list end, index within the tile
+  const uint32_t* seg_total;   // device word: number of segments of this frame
+  float* seg_P;                // [capacity, 256]    product of (1 - alpha) over the segment         (pass A)
+  float* seg_T;                // [capacity, 256]    T after the segment; < 0: pixel was dead at its entry (pass C)
+  float* seg_C;                // [capacity, C, 256] colour of the segment (C); colour behind it (after D)
+  int* seg_last;               // [capacity, 256]
+  float* seg_median;           // [capacity, 256] or NULL
+};
+
+// per-lane pixel state of the forward walk: pixel p = 2h + i, half h (rows py0 + 8h), side i (cols px0 + 8i)
+template <int C>
+struct FwdPix {
+  v2f T2[2], col2[2][3], med2[2];
+  int lastc[4];
+};
+
+// Front-to-back walk over list positions [begin, end) of one tile; `tile_start` makes the recorded last-contributor
+// index tile-relative.  A pixel is live while T >= T_eps.
+template <int C, bool VIS, bool MEDIAN>
+__device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict__ rec,
+                                         const uint32_t* __restrict__ sorted_rank,
+                                         const uint32_t* __restrict__ sorted_inst, uint32_t tile_start, uint32_t begin,
+                                         uint32_t end, float fx0, float fy0, const GsrRasterParams& rp, int lane,
+                                         float* __restrict__ vis_partial, float* __restrict__ pair_vis) {
+  // lane 16r+15 ends up with the visibility total of pair (i + {0,2,1,3}[r]) of each group of four
+  const uint32_t vis_slot = (uint32_t)(((lane >> 4) & 1) * 2 + (lane >> 5));
+  if (begin >= end) return;
+  Splat nxt = load_splat<C>(rec, sorted_rank, begin);
+  for (uint32_t i = begin; i < end; i += 4) {
+    float wq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (i + m < end) {                                               // wave-uniform
+        const Splat s = nxt;
+        if (i + m + 1 < end) nxt = load_splat<C>(rec, sorted_rank, i + m + 1);   // prefetch (scalar loads)
+        const float dxa = fx0 - s.u, dya = fy0 - s.v;
+        const v2f dx2 = {dxa, dxa + 8.f};
+        const float B2 = s.B + s.B;
+        const int idx = (int)(i - tile_start) + m + 1;
+        v2f wsum2 = GSR_V2(0.f);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (!(s.halves & (1u << h))) continue;                        // scalar test: support misses this half
+          const float dy = h ? dya + 8.f : dya;
+          const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+          const bool in0 = px.T2[h].x >= rp.T_eps && q.x <= rp.q_max;
+          const bool in1 = px.T2[h].y >= rp.T_eps && q.y <= rp.q_max;
+          if (__ballot(in0 || in1) != 0ull) {
+            const v2f G = eval_G2(q);
+            const v2f a_raw = G * s.op;
+            v2f alpha = clamp_alpha2(a_raw, rp.clamp_max_alpha);
+            const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
+            const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
+            alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
+            const v2f w = alpha * px.T2[h];
+            px.col2[h][0] = __builtin_elementwise_fma(w, GSR_V2(s.f0), px.col2[h][0]);
+            if (C > 1) px.col2[h][1] = __builtin_elementwise_fma(w, GSR_V2(s.f1), px.col2[h][1]);
+            if (C > 2) px.col2[h][2] = __builtin_elementwise_fma(w, GSR_V2(s.f2), px.col2[h][2]);
+            wsum2 += w;
+            px.T2[h] = px.T2[h] - w;                           // T (1 - alpha), with w = alpha T already formed
+            if (hit0) px.lastc[2 * h] = idx;
+            if (hit1) px.lastc[2 * h + 1] = idx;
+            if (MEDIAN) {
+              if (hit0 && px.med2[h].x == 0.f && px.T2[h].x < 0.5f) px.med2[h].x = s.depth;
+              if (hit1 && px.med2[h].y == 0.f && px.T2[h].y < 0.5f) px.med2[h].y = s.depth;
+            }
+          }
+        }
+        wq[m] = wsum2.x + wsum2.y;
+      }
+    }
+    if (VIS) {
+      // four pairs reduced at once, transposing: swap32 (4 -> 2 registers), swap16 (2 -> 1), then 4 row steps
+      float r = gsr_swap16_add(gsr_swap32_add(wq[0], wq[1]), gsr_swap32_add(wq[2], wq[3]));
+      r = gsr_row_sum_to_lane15(r);
+      const uint32_t pos = i + vis_slot;
+      if ((lane & 15) == 15 && pos < end) {
+        // sorted-position copy (read back coalesced by the backward pass) + per-instance copy (per-splat sums)
+        pair_vis[pos] = r;
+        if (r > 0.f) vis_partial[sorted_inst[pos]] = r;
+      }
+    }
+    const bool live = px.T2[0].x >= rp.T_eps || px.T2[0].y >= rp.T_eps || px.T2[1].x >= rp.T_eps ||
+                      px.T2[1].y >= rp.T_eps;
+    if (__ballot(live) == 0ull) break;
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void fwd_init(FwdPix<C>& px, int px0, int py0, int W, int H) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const bool in_y = (py0 + 8 * h) < H;            // pixels outside the image start at T = 0 and are never written
+    px.T2[h] = (v2f){(in_y && px0 < W) ? 1.f : 0.f, (in_y && (px0 + 8) < W) ? 1.f : 0.f};
+    px.med2[h] = GSR_V2(0.f);
+    px.col2[h][0] = px.col2[h][1] = px.col2[h][2] = GSR_V2(0.f);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) px.lastc[p] = 0;
+}
+
+// Pass A of a heavy tile (extra blocks of the forward launch): per-pixel product of (1 - alpha) over one segment,
+// formed with the same alpha and the same update (P -= alpha P) as the walk itself.
+template <int C>
+__device__ __forceinline__ void seg_alpha_pass(uint32_t sidx, const float* __restrict__ rec,
+                                               const uint32_t* __restrict__ sorted_rank, int tiles_x,
+                                               const GsrRasterParams& rp, const SegDev& seg) {
+  const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
+  const int tile = (int)d[0];
+  const uint32_t begin = d[1], end = d[2];
+  const int lane = (int)threadIdx.x;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const float fx0 = (float)(tx * 16 + (lane & 7)) + 0.5f, fy0 = (float)(ty * 16 + (lane >> 3)) + 0.5f;
+  v2f P2[2] = {GSR_V2(1.f), GSR_V2(1.f)};
+  Splat nxt = load_splat<1>(rec, sorted_rank, begin);
+  for (uint32_t i = begin; i < end; ++i) {
+    const Splat s = nxt;
+    if (i + 1 < end) nxt = load_splat<1>(rec, sorted_rank, i + 1);
+    const float dxa = fx0 - s.u, dya = fy0 - s.v;
+    const v2f dx2 = {dxa, dxa + 8.f};
+    const float B2 = s.B + s.B;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!(s.halves & (1u << h))) continue;
+      const float dy = h ? dya + 8.f : dya;
+      const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+      const bool in0 = q.x <= rp.q_max, in1 = q.y <= rp.q_max;
+      if (__ballot(in0 || in1) != 0ull) {
+        v2f alpha = clamp_alpha2(eval_G2(q) * s.op, rp.clamp_max_alpha);
+        alpha = (v2f){(in0 && alpha.x >= rp.alpha_threshold) ? alpha.x : 0.f,
+                      (in1 && alpha.y >= rp.alpha_threshold) ? alpha.y : 0.f};
+        P2[h] = P2[h] - alpha * P2[h];
+      }
+    }
+  }
+  float* out = seg.seg_P + 256 * (size_t)sidx + lane;
+  out[0] = P2[0].x; out[64] = P2[0].y; out[128] = P2[1].x; out[192] = P2[1].y;
+}
+
 template <int C, bool VIS, bool MEDIAN>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restrict__ rec,
                                                            const uint32_t* __restrict__ sorted_rank,
@@ -101,103 +252,150 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
                                                            float* __restrict__ image, float* __restrict__ final_T,
                                                            int* __restrict__ last, float* __restrict__ median,
                                                            float* __restrict__ vis_partial,
-                                                           float* __restrict__ pair_vis) {
+                                                           float* __restrict__ pair_vis, SegDev seg) {
+  if ((int)blockIdx.x >= num_tiles) {                                // extra blocks: pass A of the heavy tiles
+    const uint32_t sidx = blockIdx.x - (uint32_t)num_tiles;
+    if (sidx < seg.seg_total[0]) seg_alpha_pass<C>(sidx, rec, sorted_rank, tiles_x, rp, seg);
+    return;
+  }
   const int tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
+  if (seg.tile_seg && seg.tile_seg[2 * tile + 1] != 0u) return;       // heavy tile: passes A, C, D composite it
   const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
 
-  // pixel p = 2h + i : half h (rows py0 + 8h), side i (cols px0 + 8i); packed over i.
-  // A pixel is live while T >= T_eps; pixels outside the image start at T = 0 and are never written.
-  v2f T2[2], col2[2][3], med2[2];
-  int lastc[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const bool in_y = (py0 + 8 * h) < H;
-    T2[h] = (v2f){(in_y && px0 < W) ? 1.f : 0.f, (in_y && (px0 + 8) < W) ? 1.f : 0.f};
-    med2[h] = GSR_V2(0.f);
-    col2[h][0] = col2[h][1] = col2[h][2] = GSR_V2(0.f);
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) lastc[p] = 0;
-  // lane 16r+15 ends up with the visibility total of pair (i + {0,2,1,3}[r]) of each group of four
-  const uint32_t vis_slot = (uint32_t)(((lane >> 4) & 1) * 2 + (lane >> 5));
-
-  if (start < end) {
-    Splat nxt = load_splat<C>(rec, sorted_rank, start);
-    for (uint32_t i = start; i < end; i += 4) {
-      float wq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        if (i + m < end) {                                               // wave-uniform
-          const Splat s = nxt;
-          if (i + m + 1 < end) nxt = load_splat<C>(rec, sorted_rank, i + m + 1);   // prefetch (scalar loads)
-          const float dxa = fx0 - s.u, dya = fy0 - s.v;
-          const v2f dx2 = {dxa, dxa + 8.f};
-          const float B2 = s.B + s.B;
-          const int idx = (int)(i - start) + m + 1;
-          v2f wsum2 = GSR_V2(0.f);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (!(s.halves & (1u << h))) continue;                        // scalar test: support misses this half
-            const float dy = h ? dya + 8.f : dya;
-            const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
-            const bool in0 = T2[h].x >= rp.T_eps && q.x <= rp.q_max;
-            const bool in1 = T2[h].y >= rp.T_eps && q.y <= rp.q_max;
-            if (__ballot(in0 || in1) != 0ull) {
-              const v2f G = eval_G2(q);
-              const v2f a_raw = G * s.op;
-              v2f alpha = clamp_alpha2(a_raw, rp.clamp_max_alpha);
-              const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
-              const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
-              alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
-              const v2f w = alpha * T2[h];
-              col2[h][0] = __builtin_elementwise_fma(w, GSR_V2(s.f0), col2[h][0]);
-              if (C > 1) col2[h][1] = __builtin_elementwise_fma(w, GSR_V2(s.f1), col2[h][1]);
-              if (C > 2) col2[h][2] = __builtin_elementwise_fma(w, GSR_V2(s.f2), col2[h][2]);
-              wsum2 += w;
-              T2[h] = T2[h] - w;                                 // T (1 - alpha), with w = alpha T already formed
-              if (hit0) lastc[2 * h] = idx;
-              if (hit1) lastc[2 * h + 1] = idx;
-              if (MEDIAN) {
-                if (hit0 && med2[h].x == 0.f && T2[h].x < 0.5f) med2[h].x = s.depth;
-                if (hit1 && med2[h].y == 0.f && T2[h].y < 0.5f) med2[h].y = s.depth;
-              }
-            }
-          }
-          wq[m] = wsum2.x + wsum2.y;
-        }
-      }
-      if (VIS) {
-        // four pairs reduced at once, transposing: swap32 (4 -> 2 registers), swap16 (2 -> 1), then 4 row steps
-        float r = gsr_swap16_add(gsr_swap32_add(wq[0], wq[1]), gsr_swap32_add(wq[2], wq[3]));
-        r = gsr_row_sum_to_lane15(r);
-        const uint32_t pos = i + vis_slot;
-        if ((lane & 15) == 15 && pos < end) {
-          // sorted-position copy (read back coalesced by the backward pass) + per-instance copy (per-splat sums)
-          pair_vis[pos] = r;
-          if (r > 0.f) vis_partial[sorted_inst[pos]] = r;
-        }
-      }
-      const bool live = T2[0].x >= rp.T_eps || T2[0].y >= rp.T_eps || T2[1].x >= rp.T_eps || T2[1].y >= rp.T_eps;
-      if (__ballot(live) == 0ull) break;
-    }
-  }
+  FwdPix<C> px;
+  fwd_init<C>(px, px0, py0, W, H);
+  fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, start, end, fx0, fy0, rp, lane, vis_partial,
+                           pair_vis);
 
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int px = px0 + 8 * (p & 1), py = py0 + 8 * (p >> 1);
-    if (px < W && py < H) {
-      const size_t pix = (size_t)py * W + px;
+    const int x = px0 + 8 * (p & 1), y = py0 + 8 * (p >> 1);
+    if (x < W && y < H) {
+      const size_t pix = (size_t)y * W + x;
       const int h = p >> 1;
 #pragma unroll
-      for (int c = 0; c < C; ++c) image[pix * C + c] = (p & 1) ? col2[h][c].y : col2[h][c].x;
-      final_T[pix] = (p & 1) ? T2[h].y : T2[h].x;
-      last[pix] = lastc[p];
-      if (MEDIAN) median[pix] = (p & 1) ? med2[h].y : med2[h].x;
+      for (int c = 0; c < C; ++c) image[pix * C + c] = (p & 1) ? px.col2[h][c].y : px.col2[h][c].x;
+      final_T[pix] = (p & 1) ? px.T2[h].y : px.T2[h].x;
+      last[pix] = px.lastc[p];
+      if (MEDIAN) median[pix] = (p & 1) ? px.med2[h].y : px.med2[h].x;
     }
+  }
+}
+
+// Pass C of a heavy tile: the forward walk over one segment, entered with T_in = product of the preceding segments'
+// products (taken in segment order).  Outputs go to the segment's own 256-pixel slots (lane-major: slot p*64 + lane).
+template <int C, bool VIS, bool MEDIAN>
+__global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restrict__ rec,
+                                                           const uint32_t* __restrict__ sorted_rank,
+                                                           const uint32_t* __restrict__ sorted_inst,
+                                                           const uint32_t* __restrict__ tile_range, int W, int H,
+                                                           int tiles_x, GsrRasterParams rp,
+                                                           float* __restrict__ vis_partial,
+                                                           float* __restrict__ pair_vis, SegDev seg) {
+  const uint32_t sidx = blockIdx.x;
+  if (sidx >= seg.seg_total[0]) return;
+  const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
+  const int tile = (int)d[0];
+  const uint32_t begin = d[1], end = d[2];
+  const uint32_t first = seg.tile_seg[2 * tile];
+  const int lane = (int)threadIdx.x;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
+  const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
+
+  FwdPix<C> px;
+  fwd_init<C>(px, px0, py0, W, H);
+  for (uint32_t s = first; s < sidx; ++s) {
+    const float* P = seg.seg_P + 256 * (size_t)s + lane;
+    px.T2[0] = px.T2[0] * (v2f){P[0], P[64]};
+    px.T2[1] = px.T2[1] * (v2f){P[128], P[192]};
+  }
+  const bool alive[4] = {px.T2[0].x >= rp.T_eps, px.T2[0].y >= rp.T_eps, px.T2[1].x >= rp.T_eps, px.T2[1].y >= rp.T_eps};
+  if (__ballot(alive[0] || alive[1] || alive[2] || alive[3]) != 0ull)
+    fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, tile_range[2 * tile], begin, end, fx0, fy0, rp, lane,
+                             vis_partial, pair_vis);
+  const size_t o = 256 * (size_t)sidx + lane;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int h = p >> 1;
+    const float t = (p & 1) ? px.T2[h].y : px.T2[h].x;
+    seg.seg_T[o + 64 * p] = alive[p] ? t : -1.f;
+    seg.seg_last[o + 64 * p] = px.lastc[p];
+    if (MEDIAN) seg.seg_median[o + 64 * p] = (p & 1) ? px.med2[h].y : px.med2[h].x;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      seg.seg_C[(size_t)C * 256 * sidx + 256 * c + 64 * p + lane] = (p & 1) ? px.col2[h][c].y : px.col2[h][c].x;
+  }
+}
+
+// Pass D of a heavy tile: one wave per tile adds the segment colours in list order, takes T / last / median from the
+// segments that saw the pixel alive, writes the image, and replaces every segment's colour by the colour BEHIND it
+// (what its reverse walk starts from).
+template <int C, bool MEDIAN>
+__global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles_x, int num_tiles,
+                                                         float* __restrict__ image, float* __restrict__ final_T,
+                                                         int* __restrict__ last, float* __restrict__ median,
+                                                         SegDev seg) {
+  const int tile = (int)blockIdx.x;
+  const uint32_t n = seg.tile_seg[2 * tile + 1];
+  if (n == 0u) return;
+  const uint32_t first = seg.tile_seg[2 * tile];
+  const int lane = (int)threadIdx.x;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
+  float col[4][3], T[4], med[4];
+  int lastc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    col[p][0] = col[p][1] = col[p][2] = 0.f;
+    T[p] = 1.f; med[p] = 0.f; lastc[p] = 0;
+  }
+  for (uint32_t j = 0; j < n; ++j) {
+    const size_t s = first + j, o = 256 * s + lane;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float t = seg.seg_T[o + 64 * p];
+      if (t >= 0.f) T[p] = t;
+      const int l = seg.seg_last[o + 64 * p];
+      if (l != 0) lastc[p] = l;
+      if (MEDIAN) {
+        const float m = seg.seg_median[o + 64 * p];
+        if (med[p] == 0.f && m != 0.f) med[p] = m;
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) col[p][c] += seg.seg_C[(size_t)C * 256 * s + 256 * c + 64 * p + lane];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int x = px0 + 8 * (p & 1), y = py0 + 8 * (p >> 1);
+    if (x < W && y < H) {
+      const size_t pix = (size_t)y * W + x;
+#pragma unroll
+      for (int c = 0; c < C; ++c) image[pix * C + c] = col[p][c];
+      final_T[pix] = T[p];
+      last[pix] = lastc[p];
+      if (MEDIAN) median[pix] = med[p];
+    }
+  }
+  float behind[4][3];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) behind[p][0] = behind[p][1] = behind[p][2] = 0.f;
+  for (uint32_t j = n; j-- > 0u;) {
+    const size_t s = first + j;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float* cell = seg.seg_C + (size_t)C * 256 * s + 256 * c + 64 * p + lane;
+        const float own = *cell;
+        *cell = behind[p][c];
+        behind[p][c] += own;
+      }
   }
 }
 
@@ -211,8 +409,24 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
                                                            const float* __restrict__ final_T,
                                                            const int* __restrict__ last,
                                                            const float* __restrict__ dL_dimage,
-                                                           float* __restrict__ partial) {
-  const int tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
+                                                           float* __restrict__ partial, SegDev seg) {
+  // A block walks tile-relative list positions [lo, hi) in reverse: a light tile's whole list, or -- extra blocks of
+  // the launch -- one segment of a heavy tile, entered with that segment's own end state.
+  int tile, lo = 0, seg_hi = 0x7fffffff;
+  uint32_t sidx = 0u;
+  const bool is_seg = (int)blockIdx.x >= num_tiles;
+  if (is_seg) {
+    sidx = blockIdx.x - (uint32_t)num_tiles;
+    if (sidx >= seg.seg_total[0]) return;
+    const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
+    tile = (int)d[0];
+    const uint32_t tstart = tile_range[2 * tile];
+    lo = (int)(d[1] - tstart);
+    seg_hi = (int)(d[2] - tstart);
+  } else {
+    tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
+    if (seg.tile_seg && seg.tile_seg[2 * tile + 1] != 0u) return;     // heavy tile: its segments handle it
+  }
   const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
@@ -236,27 +450,35 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
     lastc[p] = 0;
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
-      const float t = final_T[pix];
+      float t = final_T[pix];
+      if (is_seg) {                                   // T after this segment (dead-at-entry pixels never contribute)
+        t = seg.seg_T[256 * (size_t)sidx + 64 * p + lane];
+        t = t < 0.f ? 1.f : t;
+      }
       if (p & 1) T2[h].y = t; else T2[h].x = t;
       lastc[p] = last[pix];
+      float gb = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float gv = dL_dimage[pix * C + c];
         if (p & 1) g2[h][c].y = gv; else g2[h][c].x = gv;
+        if (is_seg) gb = fmaf(gv, seg.seg_C[(size_t)C * 256 * sidx + 256 * c + 64 * p + lane], gb);
       }
+      if (p & 1) ga2[h].y = gb; else ga2[h].x = gb;   // g . (colour behind the segment); 0 for a whole tile
     }
     tile_last = max(tile_last, lastc[p]);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tile_last = max(tile_last, __shfl_xor(tile_last, o, 64));
   tile_last = __builtin_amdgcn_readfirstlane(tile_last);
-  if (tile_last == 0) return;
+  const int hi = min(tile_last, seg_hi);
+  if (hi <= lo) return;
   __shared__ float red[12 * 80];
   const int wslot = (lane >> 4) * 20 + (lane & 15);                  // my cell inside a value's 80-word row
   const int rslot = lane < 48 ? (lane >> 2) * 80 + (lane & 3) * 20 : 0;   // reader 4k+p: quarter p of value k
 
-  for (int cbase = ((tile_last - 1) >> 6) << 6; cbase >= 0; cbase -= 64) {
-    const int n = min(64, tile_last - cbase);
+  for (int cbase = lo + (((hi - lo - 1) >> 6) << 6); cbase >= lo; cbase -= 64) {
+    const int n = min(64, hi - cbase);
     // pairs that touched no pixel in the forward pass are skipped without evaluating anything
     // one coalesced vector load per 64 pairs for the skip flags, the packed ranks and the slot ids; a pair's
     // values are then broadcast with v_readlane (no dependent index load in front of the record fetch)
@@ -366,14 +588,100 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
   }
 }
 
+// One block plans the whole frame: a tile with more than `heavy_min` pairs is cut into ceil(len / seg_pairs) segments of
+// (almost) equal length; segments are numbered tile by tile in tile order.
+__global__ __launch_bounds__(1024) void segment_plan_kernel(const uint32_t* __restrict__ tile_range, int num_tiles,
+                                                            uint32_t seg_pairs, uint32_t heavy_min, uint32_t capacity,
+                                                            uint32_t* __restrict__ tile_seg,
+                                                            uint32_t* __restrict__ seg_desc,
+                                                            uint32_t* __restrict__ seg_total) {
+  __shared__ uint32_t s_sum[1024];
+  const int tid = (int)threadIdx.x;
+  const int per = (num_tiles + 1023) / 1024;
+  const int t0 = min(tid * per, num_tiles), t1 = min(t0 + per, num_tiles);
+  auto nseg = [&](int t) -> uint32_t {
+    const uint32_t len = tile_range[2 * t + 1] - tile_range[2 * t];
+    return len > heavy_min ? (len + seg_pairs - 1) / seg_pairs : 0u;
+  };
+  uint32_t mine = 0;
+  for (int t = t0; t < t1; ++t) mine += nseg(t);
+  s_sum[tid] = mine;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                               // inclusive scan of the per-thread counts
+    const uint32_t add = tid >= o ? s_sum[tid - o] : 0u;
+    __syncthreads();
+    s_sum[tid] += add;
+    __syncthreads();
+  }
+  uint32_t at = s_sum[tid] - mine;
+  const uint32_t total = s_sum[1023];
+  if (tid == 0) seg_total[0] = total <= capacity ? total : 0u;        // cannot exceed the bound the host sized for
+  for (int t = t0; t < t1; ++t) {
+    const uint32_t n = total <= capacity ? nseg(t) : 0u;
+    tile_seg[2 * t] = at;
+    tile_seg[2 * t + 1] = n;
+    if (n) {
+      const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
+      const uint32_t base = len / n, rem = len % n;
+      uint32_t b = a;
+      for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t e = b + base + (j < rem ? 1u : 0u);
+        uint32_t* d = seg_desc + 4 * (size_t)(at + j);
+        d[0] = (uint32_t)t; d[1] = b; d[2] = e; d[3] = j;
+        b = e;
+      }
+      at += n;
+    }
+  }
+}
+
+inline SegDev to_segdev(const GsrSegmentsC* sg) {
+  SegDev d;
+  if (sg) {
+    d.tile_seg = sg->tile_seg; d.seg_desc = sg->seg_desc; d.seg_total = sg->seg_total; d.seg_P = sg->seg_P;
+    d.seg_T = sg->seg_T; d.seg_C = sg->seg_C; d.seg_last = sg->seg_last; d.seg_median = sg->seg_median;
+  } else {
+    d.tile_seg = nullptr; d.seg_desc = nullptr; d.seg_total = nullptr; d.seg_P = nullptr; d.seg_T = nullptr;
+    d.seg_C = nullptr; d.seg_last = nullptr; d.seg_median = nullptr;
+  }
+  return d;
+}
+
+inline bool seg_ok(const GsrSegmentsC* sg, bool median) {
+  if (!sg) return true;
+  if (sg->capacity <= 0) return false;
+  return sg->tile_seg && sg->seg_desc && sg->seg_total && sg->seg_P && sg->seg_T && sg->seg_C && sg->seg_last &&
+         (!median || sg->seg_median);
+}
+
 }  // namespace
 
 extern "C" {
 
+int64_t gsr_segment_capacity(int64_t O, int32_t seg_pairs, int32_t heavy_min) {
+  if (O <= 0 || seg_pairs <= 0 || heavy_min < seg_pairs) return 0;
+  // a heavy tile of len pairs (len > heavy_min) yields ceil(len / seg_pairs) <= len / seg_pairs + 1 segments
+  return O / seg_pairs + O / ((int64_t)heavy_min + 1) + 1;
+}
+
+int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs, int32_t heavy_min,
+                     int64_t capacity, uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out,
+                     void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (num_tiles <= 0 || seg_pairs <= 0 || heavy_min < seg_pairs || capacity <= 0 || capacity > 0x7fffffffll)
+    return GSR_ERR_INVALID_ARGUMENT;
+  if (!tile_range || !tile_seg_out || !seg_desc_out || !seg_total_out) return GSR_ERR_INVALID_ARGUMENT;
+  segment_plan_kernel<<<1, 1024, 0, stream>>>(tile_range, num_tiles, (uint32_t)seg_pairs, (uint32_t)heavy_min,
+                                             (uint32_t)capacity, tile_seg_out, seg_desc_out, seg_total_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
 int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
                           const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                           const GsrRasterParamsC* params_host, float* image_out, float* final_T_out, int32_t* last_out,
-                          float* median_depth_out, float* vis_partial_out, float* pair_vis_out, void* stream_) {
+                          float* median_depth_out, float* vis_partial_out, float* pair_vis_out,
+                          const GsrSegmentsC* segments_host, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16 || C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
@@ -382,10 +690,22 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
   const GsrRasterParams rp = to_params(params_host);
   const bool vis = vis_partial_out != nullptr, med = median_depth_out != nullptr;
   if (vis && !pair_vis_out) return GSR_ERR_INVALID_ARGUMENT;
-#define GSR_LAUNCH_FWD(CC, VV, MM)                                                                                  \
-  composite_fwd_kernel<CC, VV, MM><<<nt, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, tx, nt, \
-                                                          rp, image_out, final_T_out, last_out, median_depth_out,  \
-                                                          vis_partial_out, pair_vis_out)
+  if (!seg_ok(segments_host, med)) return GSR_ERR_INVALID_ARGUMENT;
+  const SegDev seg = to_segdev(segments_host);
+  const int cap = segments_host ? (int)segments_host->capacity : 0;
+#define GSR_LAUNCH_FWD(CC, VV, MM)                                                                                     \
+  do {                                                                                                                 \
+    composite_fwd_kernel<CC, VV, MM><<<nt + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, tx, \
+                                                                  nt, rp, image_out, final_T_out, last_out,            \
+                                                                  median_depth_out, vis_partial_out, pair_vis_out,     \
+                                                                  seg);                                                \
+    if (cap) {                                                                                                         \
+      seg_composite_kernel<CC, VV, MM><<<cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, tx,    \
+                                                               rp, vis_partial_out, pair_vis_out, seg);                \
+      seg_combine_kernel<CC, MM><<<nt, 64, 0, stream>>>(W, H, tx, nt, image_out, final_T_out, last_out,                \
+                                                        median_depth_out, seg);                                        \
+    }                                                                                                                  \
+  } while (0)
 #define GSR_DISPATCH_FWD(CC)                                       \
   do {                                                             \
     if (vis && med) GSR_LAUNCH_FWD(CC, true, true);                \
@@ -405,16 +725,20 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
 int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
                            const float* pair_vis, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                            const GsrRasterParamsC* params_host, const float* final_T, const int32_t* last,
-                           const float* dL_dimage, float* partial_out, void* stream_) {
+                           const float* dL_dimage, float* partial_out, const GsrSegmentsC* segments_host,
+                           void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16 || C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
   if (!tile_range || !final_T || !last || !dL_dimage) return GSR_ERR_INVALID_ARGUMENT;
+  if (!seg_ok(segments_host, false)) return GSR_ERR_INVALID_ARGUMENT;
   const int tx = (W + 15) / 16, ty = (H + 15) / 16, nt = tx * ty;
   const GsrRasterParams rp = to_params(params_host);
-  if (C == 1) composite_bwd_kernel<1><<<nt, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out);
-  else if (C == 2) composite_bwd_kernel<2><<<nt, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out);
-  else composite_bwd_kernel<3><<<nt, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out);
+  const SegDev seg = to_segdev(segments_host);
+  const int grid = nt + (segments_host ? (int)segments_host->capacity : 0);
+  if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out, seg);
+  else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out, seg);
+  else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out, seg);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -33,6 +33,8 @@ class RasterConfig:
   aa_blur: float = 0.3                # anti-alias filter variance (px^2) used when antialias=True
   compute_visibility: bool = False    # fill points.visibility (sum_pixels T*alpha) in forward
   compute_point_heuristic: bool = False  # fill prune_cost / split_score in backward
+  segment_pairs: int = 256            # heavy tiles: list segments of at most this many (tile, splat) pairs; 0 = off
+  segment_min_pairs: int = 512        # a tile is heavy (its list is segmented) above this many pairs
 
   @property
   def transmittance_eps(self) -> float:

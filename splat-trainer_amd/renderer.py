@@ -221,7 +221,8 @@ class _RasterState:
   """Per-frame buffers shared by forward and backward (owned by the autograd node / the Rendering)."""
   __slots__ = ("M", "O", "C", "W", "H", "params", "rec", "order", "count", "offsets", "sorted_rank",
                "sorted_inst", "tile_range", "vis_partial", "pair_vis", "final_T", "last", "median", "visibility",
-               "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad")
+               "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad",
+               "segments", "segment_buffers", "seg_pairs", "seg_min")
 
 
 def _u32(n: int, device) -> torch.Tensor:
@@ -240,6 +241,36 @@ def _launch_depth_order(depth: torch.Tensor, M: int) -> torch.Tensor:
   where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, 32,
                                             _ptr(sort_ws), sort_bytes, stream), "gsr_sort_pairs_u32(depth)")
   return vals_b if where == 1 else vals_a
+
+
+def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream):
+  """Heavy-tile list segmentation (composite.hip): tiles with more than ``segment_min_pairs`` pairs are cut into
+  segments of at most ``segment_pairs``; returns the GsrSegmentsC the composite calls take, or None when switched off.
+  The tables are sized from a host-side bound on the segment count, so no extra sync is needed."""
+  st.segment_buffers = None
+  if st.seg_pairs <= 0:
+    return None
+  lib = _lib.load()
+  cap = int(lib.gsr_segment_capacity(O, st.seg_pairs, st.seg_min))
+  if cap <= 0:
+    return None
+  tables = torch.empty(2 * num_tiles + 4 * cap + 1, dtype=torch.int32, device=dev)
+  tile_seg, seg_desc, seg_total = tables[:2 * num_tiles], tables[2 * num_tiles:2 * num_tiles + 4 * cap], tables[-1:]
+  _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, st.seg_pairs, st.seg_min, cap, _ptr(tile_seg),
+                                  _ptr(seg_desc), _ptr(seg_total), stream), "gsr_segment_plan")
+  planes = 2 + st.C + (1 if st.want_median else 0)
+  pix = torch.empty(planes * cap * 256, dtype=torch.float32, device=dev)
+  seg_last = torch.empty(cap * 256, dtype=torch.int32, device=dev)
+  seg_P, seg_T, seg_C = pix[:cap * 256], pix[cap * 256:2 * cap * 256], pix[2 * cap * 256:(2 + st.C) * cap * 256]
+  seg_med = pix[(2 + st.C) * cap * 256:] if st.want_median else None
+  st.segment_buffers = (tables, pix, seg_last)                      # kept alive until backward has run
+  return _lib.GsrSegmentsC(tile_seg.data_ptr(), seg_desc.data_ptr(), seg_total.data_ptr(), cap, seg_P.data_ptr(),
+                           seg_T.data_ptr(), seg_C.data_ptr(), seg_last.data_ptr(),
+                           seg_med.data_ptr() if seg_med is not None else None)
+
+
+def _seg_ref(st: "_RasterState"):
+  return C.byref(st.segments) if st.segments is not None else None
 
 
 def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tensor, st: _RasterState,
@@ -321,13 +352,14 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
 
   st.vis_partial = zeros[2 * M + 2 * num_tiles:] if need_vis_partial else None
   st.pair_vis = torch.empty(O, dtype=torch.float32, device=dev) if need_vis_partial else None
+  st.segments = _plan_segments(st, num_tiles, O, dev, stream)
   timer = KERNEL_TIMER
   if timer is not None:
     timer.begin("composite_forward")
   _lib.check(lib.gsr_composite_forward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
                                        _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
                                        _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
-                                       _ptr(st.pair_vis), stream), "gsr_composite_forward")
+                                       _ptr(st.pair_vis), _seg_ref(st), stream), "gsr_composite_forward")
   if timer is not None:
     timer.end("composite_forward")
   if st.compute_visibility:
@@ -366,7 +398,7 @@ class _RasterFn(torch.autograd.Function):
       _lib.check(lib.gsr_composite_backward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
                                             _ptr(st.pair_vis), _ptr(st.tile_range), st.W, st.H, st.C,
                                             C.byref(st.params), _ptr(st.final_T), _ptr(st.last), _ptr(dimg),
-                                            _ptr(partial), stream), "gsr_composite_backward")
+                                            _ptr(partial), _seg_ref(st), stream), "gsr_composite_backward")
       if timer is not None:
         timer.end("composite_backward")
       # prune_cost / split_score are written straight into the tensors the Rendering already holds
@@ -399,6 +431,9 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
   st.compute_visibility = bool(config.compute_visibility or config.compute_point_heuristic)
   st.vis_partial = None
   st.pair_vis = None
+  st.segments = None
+  st.segment_buffers = None
+  st.seg_pairs, st.seg_min = int(config.segment_pairs), int(max(config.segment_min_pairs, config.segment_pairs))
   st.needs_grad = torch.is_grad_enabled() and (gaussians2d.requires_grad or features.requires_grad)
   order = None
   if _depth_order is not None and _depth_order[1] is depth and _depth_order[2] == depth._version:

@@ -23,3 +23,26 @@ def built_libs():
 @pytest.fixture(scope="session")
 def golden_dir():
   return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_terminal_summary(terminalreporter):
+  """Observed parity numbers (tests/helpers.py: PARITY_LOG), printed and kept under gpurun_out/."""
+  try:
+    from helpers import PARITY_LOG
+  except Exception:
+    return
+  if not PARITY_LOG:
+    return
+  lines = [f"{'case':58s} {'tensor':14s} {'max rel err':>12s} {'> tol':>9s} {'of':>10s} {'tol':>8s}"]
+  for label, key, worst, above, n, tol in PARITY_LOG:
+    lines.append(f"{label[:58]:58s} {key:14s} {worst:12.3e} {above:9d} {n:10d} {tol:8.0e}")
+  terminalreporter.write_sep("-", "observed parity (HIP vs oracle, relative to each tensor's max magnitude)")
+  for ln in lines:
+    terminalreporter.write_line(ln)
+  out_dir = os.path.join(ROOT, "gpurun_out")
+  try:
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_observed.txt"), "w") as f:
+      f.write("\n".join(lines) + "\n")
+  except OSError:
+    pass

@@ -1,0 +1,114 @@
+"""Heavy-tile list segmentation (composite.hip passes A/C/D + segment blocks of the backward launch): a tile whose list
+is cut into segments must give the oracle's image, per-point sums and gradients, agree with the one-wave-per-tile walk
+to rounding, stay bit-reproducible, and remove the heavy-tile bound on clustered scenes."""
+import math
+import time
+
+import pytest
+import torch
+
+import splat_trainer_amd as sta
+from helpers import compare_to_oracle, hip_render_and_grads, observe, oracle_render_and_grads, rel_err, small_scene
+from splat_trainer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+KEYS = ("image", "final_T", "visibility", "prune_cost", "split_score", "d_position", "d_log_scaling", "d_rotation",
+        "d_alpha_logit", "d_feature")
+
+
+def _cfg(seg, seg_min=None):
+  return sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True, segment_pairs=seg,
+                          segment_min_pairs=seg if seg_min is None else seg_min)
+
+
+@pytest.mark.parametrize("seg", [1, 5, 8, 64])
+@pytest.mark.parametrize("sh_degree,w,h,n", [(0, 64, 48, 500), (2, 50, 37, 900)])
+def test_forced_segments_match_oracle(seg, sh_degree, w, h, n):
+  """Tiny segments force every tile with more than `seg` pairs through passes A/C/D and the segment backward."""
+  g, cam = small_scene(n, w, h, sh_degree=sh_degree, seed=11 + sh_degree, sigma_px=3.0)
+  hip = hip_render_and_grads(g, cam, _cfg(seg), use_sh=True, want_median=True)
+  orc = oracle_render_and_grads(g, cam, _cfg(seg), use_sh=True, want_median=True)
+  compare_to_oracle(f"segments seg={seg} sh{sh_degree} {w}x{h} n={n}", hip, orc, 1e-4)
+  assert rel_err(hip["median"], orc["median"]) < 1e-5
+
+
+def test_segmented_equals_unsegmented_to_rounding_and_is_reproducible():
+  g, cam = small_scene(1500, 96, 80, sh_degree=1, seed=5, sigma_px=3.0)
+  whole = hip_render_and_grads(g, cam, _cfg(0), use_sh=True, want_median=True)
+  cut = hip_render_and_grads(g, cam, _cfg(16, 32), use_sh=True, want_median=True)
+  again = hip_render_and_grads(g, cam, _cfg(16, 32), use_sh=True, want_median=True)
+  for k in KEYS + ("median",):
+    worst, _ = observe("segmented vs one wave per tile", k, cut[k], whole[k], 1e-5)
+    assert worst < 2e-5, (k, worst)                 # association order of the T product / colour sum only
+    assert torch.equal(cut[k], again[k]), k          # fixed order everywhere: bit-reproducible
+  assert torch.equal(cut["rendering"].points.idx, whole["rendering"].points.idx)
+
+
+def test_saturating_stack_of_opaque_splats():
+  """Many opaque splats on one tile: pixels die inside early segments, later segments must be skipped, final T / last
+  contributor / gradients must come from the segment in which each pixel died."""
+  torch.manual_seed(0)
+  n = 600
+  g, cam = small_scene(n, 32, 32, sh_degree=0, seed=2, sigma_px=6.0)
+  g.alpha_logit[:] = 4.0                                          # opacity 0.98
+  hip = hip_render_and_grads(g, cam, _cfg(8), use_sh=True)
+  orc = oracle_render_and_grads(g, cam, _cfg(8), use_sh=True)
+  compare_to_oracle("segments, saturating opaque stack", hip, orc, 1e-4)
+  assert float(hip["final_T"].max()) < 1e-3
+
+
+def _clustered(n, w, h, frac, region, seed=0):
+  g, cam = synthetic.scene_a(n, w, h, sh_degree=0, seed=seed)
+  k = int(frac * n)
+  gen = torch.Generator().manual_seed(1)
+  fx = w / (2.0 * math.tan(math.radians(30.0)))
+  z = g.position[:k, 2]
+  u = (0.5 + region * (torch.rand(k, generator=gen) - 0.5)) * w
+  v = (0.5 + region * (torch.rand(k, generator=gen) - 0.5)) * h
+  g.position[:k, 0] = (u - w / 2) * z / fx
+  g.position[:k, 1] = (v - h / 2) * z / fx
+  return g, cam
+
+
+def test_clustered_scene_matches_oracle_with_default_thresholds():
+  """Half of 20k splats packed into the central 10 % x 10 % of a 320x240 image: ~ 4 tiles carry lists of thousands of
+  pairs and are segmented by the default thresholds (256 / 512)."""
+  g, cam = _clustered(20_000, 320, 240, 0.5, 0.1)
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  hip = hip_render_and_grads(g, cam, cfg, use_sh=True)
+  orc = oracle_render_and_grads(g, cam, cfg, use_sh=True)
+  compare_to_oracle("clustered 20k 320x240 (default segments)", hip, orc, 1e-4)
+
+
+def test_clustered_full_size_time_is_bounded():
+  """500k splats at 1080p, half of them in the central 10 % x 10 %: K6 + K7 with segmentation stay within 2x the
+  uniform scene (they were 3.7x without)."""
+  from splat_trainer_amd import renderer
+  times = {}
+  for name, frac, region in (("uniform", 0.0, 1.0), ("clustered", 0.5, 0.1)):
+    g, cam = _clustered(500_000, 1920, 1080, frac, region)
+    g, cam = g.to("cuda"), cam.to("cuda")
+    cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+    params = [t.requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+    scene = sta.Gaussians3D(position=params[0], log_scaling=params[1], rotation=params[2], alpha_logit=params[3],
+                            feature=params[4])
+
+    def step():
+      with torch.enable_grad():
+        r = sta.render_gaussians(scene, cam, cfg, use_sh=True)
+        ((r.image - 0.5) ** 2).mean().backward()
+      return r
+    for _ in range(3):
+      step()
+    torch.cuda.synchronize()
+    timer = renderer.KernelTimer()
+    renderer.KERNEL_TIMER = timer
+    try:
+      for _ in range(5):
+        step()
+      ks = timer.summary()
+    finally:
+      renderer.KERNEL_TIMER = None
+    times[name] = (ks["composite_forward"][1], ks["composite_backward"][1])
+    print(f"{name}: K6 {times[name][0] * 1e3:.0f} us  K7 {times[name][1] * 1e3:.0f} us")
+  assert sum(times["clustered"]) <= 2.0 * sum(times["uniform"]), times

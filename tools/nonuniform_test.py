@@ -1,13 +1,15 @@
 """Tile-load imbalance: K6/K7 time on a clustered scene (a fraction of the splats packed into a small image region)
-against the uniform scene of the same size.  One wave walks one tile's list serially, so the heaviest tile bounds both
-kernels from below."""
+against the uniform scene of the same size, with and without heavy-tile list segmentation.  Without it one wave walks
+one tile's list serially, so the heaviest tile bounds both kernels from below."""
 import sys, math, torch
 sys.path.insert(0, ".")
 import splat_trainer_amd as sta
 from splat_trainer_amd import synthetic, renderer
 W, H, n = 1920, 1080, 500_000
-cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
-for frac, region in [(0.0, 1.0), (0.3, 0.2), (0.5, 0.1), (0.5, 0.05)]:
+import itertools
+CFGS = {"segmented (256/512)": sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True),
+        "one wave per tile": sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True, segment_pairs=0)}
+for (frac, region), (cfg_name, cfg) in itertools.product([(0.0, 1.0), (0.3, 0.2), (0.5, 0.1), (0.5, 0.05)], CFGS.items()):
   g, cam = synthetic.scene_a(n, W, H, sh_degree=0, seed=0)
   k = int(frac * n)
   if k:
@@ -32,5 +34,5 @@ for frac, region in [(0.0, 1.0), (0.3, 0.2), (0.5, 0.1), (0.5, 0.05)]:
   for _ in range(10): r = step()
   torch.cuda.synchronize(); renderer.KERNEL_TIMER = None
   ks = timer.summary()
-  print(f"{frac:.0%} of the splats in the central {region:.0%} x {region:.0%} of the image: O {r.num_overlaps}  "
-        f"K6 {ks['composite_forward'][1] * 1e3:.0f} us  K7 {ks['composite_backward'][1] * 1e3:.0f} us")
+  print(f"{frac:.0%} of the splats in the central {region:.0%} x {region:.0%} of the image, {cfg_name}: O {r.num_overlaps}  "
+        f"K6 {ks['composite_forward'][1] * 1e3:.0f} us  K7 {ks['composite_backward'][1] * 1e3:.0f} us", flush=True)

@@ -32,6 +32,12 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s peak, ~6.3 TB/s achievable)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X spec, packed fp32 FMA on every lane (MI355X_MICROARCH.md)
+# Issue cost of one wave64 VALU instruction per SIMD at >= 6 waves per SIMD, nanoseconds of wall time, measured on the
+# MI355X with tools/valu_rate.hip (profiles/r02_valu_issue_costs.txt): the chip lowers its clock under a full VALU load,
+# so the costs are quoted in time, not cycles.  plain = v_fma/v_mul/v_add/v_cmp/v_cndmask, packed = v_pk_{fma,mul,add}_f32,
+# trans = v_exp/v_rcp/v_sqrt.
+VALU_ISSUE_NS = {"valu": 1.35, "valu_packed": 1.95, "valu_trans": 4.1}
 
 WORKLOADS = {
     "c1": dict(scene="A", n=10_000, w=256, h=256, sh=0),
@@ -60,6 +66,55 @@ def make_workload(name: str, world: int):
   else:
     g, cams = synthetic.scene_b(w["n"], w["w"], w["h"], sh_degree=w["sh"], seed=1, num_cameras=max(world, 8))
   return g, cams, w
+
+
+def measure_copy_bandwidth(dev, mib: int = 1024, reps: int = 5) -> float:
+  """Device-to-device copy bandwidth (GB/s, read + write bytes) of this GPU: the practical HBM ceiling next to the
+  8 TB/s datasheet figure."""
+  n = mib * (1 << 20) // 4
+  src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+  dst = torch.empty_like(src)
+  dst.copy_(src)
+  torch.cuda.synchronize()
+  best = float("inf")
+  for _ in range(reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    best = min(best, e0.elapsed_time(e1))
+  del src, dst
+  return 2.0 * n * 4 / (best * 1e-3) / 1e9
+
+
+def newest_profile(pattern: str):
+  import glob
+  hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+  return hits[-1] if hits else None
+
+
+def valu_roofline(kernel_key: str, isa_key: str, pmc: dict, ms: float, pairs: int):
+  """VALU-issue roofline of one composite kernel: wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, kept in
+  profiles/) priced with the measured issue costs in the static packed / plain / transcendental proportions of the
+  kernel's per-pair loop (tools/isa_stats.py), against the measured launch time; plus the fp32 rate those instructions
+  amount to against the 157.3 TFLOP/s vector peak (2 flops per fma lane, packed ops count twice)."""
+  try:
+    insts = float(pmc["kernels"][kernel_key]["SQ_INSTS_VALU"])
+    mix = pmc["isa"][isa_key]["static_loop_mix"]
+  except Exception:   # noqa: BLE001
+    return None
+  tot = sum(mix.get(k, 0) for k in VALU_ISSUE_NS)
+  if not tot or not ms or ms != ms:
+    return None
+  ns = sum(mix.get(k, 0) * c for k, c in VALU_ISSUE_NS.items()) / tot
+  bound_ms = insts * ns * 1e-9 / 1024 * 1e3                      # 1024 SIMDs
+  lane_flops = insts * 64 * 2 * (1.0 + mix.get("valu_packed", 0) / tot)
+  return {"valu_insts_per_launch": insts, "valu_insts_per_pair": insts / max(pairs, 1), "mean_issue_ns_per_inst": ns,
+          "issue_bound_ms": bound_ms, "frac_of_issue_bound": bound_ms / ms,
+          "fp32_tflops_issued": lane_flops / (ms * 1e-3) / 1e12, "fp32_vector_peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+          "frac_of_fp32_vector_peak": lane_flops / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+          "mix_source": "tools/isa_stats.py static loop mix + tools/valu_rate.hip issue costs (profiles/r02_valu_issue_costs.txt)"}
 
 
 def cpu_baseline(g, cam, cfg, budget_s: float = 25.0, chunk_tiles: int = 1024):
@@ -203,17 +258,24 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  copy_gbs = measure_copy_bandwidth(dev) if rank == 0 else None
   for _ in range(args.warmup):
     step()
   sync()
   timer = renderer.KernelTimer()
   renderer.KERNEL_TIMER = timer
+  marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  marks[0].record()
+  for i in range(args.steps):
     step()
+    marks[i + 1].record()
   sync()
   elapsed = time.perf_counter() - t0
   renderer.KERNEL_TIMER = None
+  per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+  median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else \
+      0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
   if world > 1:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -239,43 +301,66 @@ def main():
   ksum = timer.summary()
   n_bwd, ms_bwd = ksum.get("composite_backward", (0, float("nan")))
   n_fwd, ms_fwd = ksum.get("composite_forward", (0, float("nan")))
+  K = (w["sh"] + 1) ** 2
+  B_par = 44 + 12 * K
   alg_bytes_bwd = 40 * O + 32 * P + 36 * M                 # (S+I) O + 32 P + S M
-  # HBM traffic of K7 from PMC counters cannot be collected from inside this process; the value measured with
-  # rocprofv3 on the same command (separate --pmc passes) is kept under profiles/ and quoted when the workload matches
-  traffic, valu_insts = None, None
+  alg_bytes_fwd = 40 * O + 20 * P                          # (S+I) O + 20 P
+  alg_bytes_step = 12 * N + (3 * B_par + 104) * M + 104 * O + 52 * P
+  # HBM traffic / VALU counters of the kernels cannot be collected from inside this process; the values measured with
+  # rocprofv3 on the same command (separate --pmc passes) are kept under profiles/ and quoted when the workload matches
+  pmc, pmc_path = None, newest_profile(f"r*_pmc_{args.workload}.json")
   try:
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_c2.json")))
-    if pmc.get("workload") == args.workload:
-      traffic = pmc["kernels"]["K7"]["hbm_bytes_per_launch"]
-      valu_insts = pmc["kernels"]["K7"].get("SQ_INSTS_VALU")
+    pmc = json.load(open(pmc_path)) if pmc_path else None
   except Exception:   # noqa: BLE001
-    traffic = None
-  achieved = alg_bytes_bwd / (ms_bwd * 1e-3) / 1e9 if n_bwd else float("nan")
+    pmc = None
+  pmc_name = os.path.relpath(pmc_path, ROOT) if pmc else None
+
+  def traffic_of(key):
+    try:
+      return pmc["kernels"][key]["hbm_bytes_per_launch"]
+    except Exception:   # noqa: BLE001
+      return None
+
+  def line(alg_bytes, ms, traffic=None):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms == ms and ms > 0 else float("nan")
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "frac_of_measured_copy_bw": (gbs / copy_gbs) if copy_gbs else None, "traffic": traffic,
+            "algorithmic_bytes": alg_bytes, "avg_ms": ms}
+
   cameras_per_step = world
   value = N * cameras_per_step * args.steps / elapsed
+  step_ms = 1e3 * elapsed / args.steps
 
   if rank == 0:
+    k7 = line(alg_bytes_bwd, ms_bwd, traffic_of("K7"))
+    k7.update({"kernel": "composite_bwd_kernel<3> (K7 alpha-composite backward)", "launches_timed": n_bwd,
+               "algorithmic_bytes_per_launch": alg_bytes_bwd, "avg_launch_ms": ms_bwd,
+               "traffic_source": f"{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, uncorrected)"
+               if traffic_of("K7") else None,
+               "hbm_copy_gbs_measured": copy_gbs,
+               # K7 / K6 are bound by VALU issue, not by HBM: the second roofline states that bound
+               "valu": valu_roofline("K7", "K7_bwd_C3", pmc, ms_bwd, O) if pmc else None,
+               "kernels": {
+                   "K6 composite_fwd_kernel<3,vis> (alpha-composite forward, incl. heavy-tile passes)":
+                       dict(line(alg_bytes_fwd, ms_fwd, traffic_of("K6")),
+                            valu=valu_roofline("K6", "K6_fwd_C3_vis", pmc, ms_fwd, O) if pmc else None),
+                   "whole step (cull -> project -> SH -> bin -> sort -> composite -> loss -> backward)":
+                       line(alg_bytes_step * len(my_cams), median_ms)}})
     out = {
         "metric": "fwd+bwd Gaussians/s", "value": value, "unit": "Gaussians/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "ms_per_step_median": median_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, "
                                f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on",
                    "gaussians": N, "visible": M, "tile_overlaps": O, "pixels": P, "cameras_per_step": cameras_per_step,
-                   "parallelism": (f"dp{world} (camera-sharded, all_reduce of {bucket.flat.numel() * 4 / 1e6:.0f} MB geometry "
+                   "parallelism": ("dp1 (one GPU: gradients accumulate in place, no collective)" if world == 1 else
+                                   f"dp{world} (camera-sharded, all_reduce of {bucket.flat.numel() * 4 / 1e6:.0f} MB geometry "
                                    f"grads + all_gather of {world * N * 12 / 1e6:.0f} MB colour-gradient factors)" if factor_mode else
                                    f"dp{world} (camera-sharded, fused {args.collective} of {bucket.flat.numel() * 4 / 1e6:.0f} MB grads)"),
-                   "psnr_note": "parity vs CPU oracle is asserted by tests/test_gpu_render.py (PSNR > 100 dB on c1)"},
-        "roofline": {"bound": "hbm", "kernel": "composite_bwd_kernel<3> (K7 alpha-composite backward)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_c2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, uncorrected)" if traffic else None,
-                     "algorithmic_bytes_per_launch": alg_bytes_bwd,
-                     "avg_launch_ms": ms_bwd, "launches_timed": n_bwd,
-                     "composite_forward_avg_ms": ms_fwd,
-                     # the kernel is bound by VALU issue, not by HBM: wave64 VALU instructions of one
-                     # launch (rocprofv3 SQ_INSTS_VALU, same PMC file) x ~4.5 SIMD cycles each over 1024 SIMDs at 2.4 GHz
-                     "valu_insts_per_launch": valu_insts,
-                     "valu_busy_frac_est": (valu_insts * 4.5 / (1024 * 2.4e9) / (ms_bwd * 1e-3)) if (valu_insts and n_bwd) else None},
+                   "parity": "parity unpinned by the reference (its rasterizer is an absent third-party package); "
+                             "HIP vs this build's fp64 oracle is asserted by tests/ (-m gpu), observed errors in "
+                             "profiles/r02_parity_observed.txt"},
+        "roofline": k7,
     }
     if check is not None:
       out["config"]["collective_check_rel_err"] = check

@@ -70,7 +70,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 11) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 12) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -230,6 +230,32 @@ int gsr_opt_point_weights(const int64_t* indexes, const float* visibility, int64
 int gsr_opt_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* indexes,
                  const float* row_scale, const float* basis, int64_t M, int32_t D, int32_t type, int32_t algo, float lr,
                  float beta1, float beta2, float eps, float grad_clip, void* stream);
+
+/* ---- densify / prune support next to the path ------------------------------------------
+ *      deterministic top-n mask replacing take_n = argsort(t)[:n] -> mask (splat_trainer/controller/target_controller.py:
+ *      150-160) and fused keep-mask compaction + append of all per-point columns (scene.split_and_prune,
+ *      splat_trainer/scene/mlp_scene.py:301-310; controller/point_state.py:76-110). -------------------------------- */
+size_t gsr_select_workspace_bytes(int64_t N);
+/* mask_out [N] bytes (0/1): the n smallest values (descending = 0) or the n largest (descending = 1); among equal
+ * values the lowest indexes are taken (what a stable argsort gives); NaN orders above +inf, -0 equals +0. */
+int gsr_select_n(const float* values, int64_t N, int64_t n, int32_t descending, uint8_t* mask_out, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+#define GSR_MAX_COLUMNS 32
+typedef struct GsrColumnC {
+  const void* src;       /* [N, width] 4-byte words: the column before compaction */
+  void* dst;             /* [kept + n_tail, width]: kept rows in order, then the appended rows */
+  const void* tail;      /* [n_tail, width] appended rows, or NULL: the appended rows are zero-filled */
+  int32_t width_dwords;
+} GsrColumnC;
+size_t gsr_compact_workspace_bytes(int64_t N);
+/* keep_mask [N] bytes.  block_offsets_out [ceil(N/256)] = kept rows before each block of 256 source rows;
+ * kept_total_dev = number of kept rows (read it back to size the destination columns). */
+int gsr_compact_offsets(const uint8_t* keep_mask, int64_t N, uint32_t* block_offsets_out, uint32_t* kept_total_dev,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* One launch moves every column: kept rows to dst[0, kept), tail rows (or zeros) to dst[kept, kept + n_tail). */
+int gsr_compact_columns(const uint8_t* keep_mask, int64_t N, const uint32_t* block_offsets, int64_t kept_total,
+                        int64_t n_tail, const GsrColumnC* columns_host, int32_t n_columns, void* stream);
 
 #ifdef __cplusplus
 }

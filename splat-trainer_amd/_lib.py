@@ -9,9 +9,10 @@ import os
 import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
+# GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
+LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class GsrRasterParamsC(C.Structure):
@@ -24,6 +25,13 @@ class GsrSegmentsC(C.Structure):
   _fields_ = [("tile_seg", C.c_void_p), ("seg_desc", C.c_void_p), ("seg_total", C.c_void_p), ("capacity", C.c_int64),
               ("seg_P", C.c_void_p), ("seg_T", C.c_void_p), ("seg_C", C.c_void_p), ("seg_last", C.c_void_p),
               ("seg_median", C.c_void_p)]
+
+
+class GsrColumnC(C.Structure):
+  _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("tail", C.c_void_p), ("width_dwords", C.c_int32)]
+
+
+MAX_COLUMNS = 32
 
 
 def raster_params(config) -> GsrRasterParamsC:
@@ -70,6 +78,11 @@ PROTOTYPES = {
     "gsr_ssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "gsr_ssim_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gsr_ssim_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    "gsr_select_workspace_bytes": (_sz, [_i64]),
+    "gsr_select_n": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "gsr_compact_workspace_bytes": (_sz, [_i64]),
+    "gsr_compact_offsets": (C.c_int, [_p, _i64, _p, _p, _p, _sz, _p]),
+    "gsr_compact_columns": (C.c_int, [_p, _i64, _p, _i64, _i64, C.POINTER(GsrColumnC), _i32, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
 }

@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
 HOSTMATH_PATH = os.path.join(PKG_DIR, "libgsr_hostmath.so")
-HIP_SOURCES = ["prims.hip", "geometry.hip", "binning.hip", "composite.hip", "ssim.hip", "optim.hip"]
+HIP_SOURCES = ["prims.hip", "geometry.hip", "binning.hip", "composite.hip", "ssim.hip", "optim.hip", "densify.hip"]
 HEADERS = ["gsr_math.h", "gsr_device.h", "gsr_dpp_reduce.h", os.path.join("..", "..", "include", "gsplat_hip.h")]
 
 
@@ -35,17 +35,18 @@ def _hipcc() -> str:
   return exe
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
+def build_hip(force: bool = False, verbose: bool = False, out: str = LIB_PATH, defines=()) -> str:
+  """``out`` / ``defines``: experimental variants (``-DNAME[=v]``) built next to the product library."""
   srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
   deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-  if not force and _newer(LIB_PATH, deps):
-    return LIB_PATH
+  if not force and _newer(out, deps):
+    return out
   cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-         "-Wno-unused-value", "-o", LIB_PATH] + srcs
+         "-Wno-unused-value", "-o", out] + [f"-D{d}" for d in defines] + srcs
   if verbose:
     print(" ".join(cmd), flush=True)
   subprocess.run(cmd, check=True, cwd=CSRC)
-  return LIB_PATH
+  return out
 
 
 def build_hostmath(force: bool = False, verbose: bool = False) -> str:

@@ -53,8 +53,14 @@ class PointState:
 
 
 def take_n(t: torch.Tensor, n: int, descending: bool = False) -> torch.Tensor:
-  """Bool mask of the n smallest (largest) entries.  The reference uses a non-stable argsort; the
-  harness uses a stable one so ties resolve identically for HIP and oracle inputs."""
+  """Bool mask of the n smallest (largest) entries (target_controller.py:150-160).  The reference's non-stable argsort
+  leaves the choice among equal values (zeros and infs by the thousand) to the sort implementation; here ties go to the
+  lowest indexes.  On the device this is the radix-select kernel (densify.select_n); on the CPU -- the oracle side of
+  the mask-parity tests -- a stable argsort, which makes the same choice."""
+  assert n >= 0, f"n must be >= 0, got {n}"
+  if t.is_cuda:
+    from .densify import select_n
+    return select_n(t, n, descending=descending)
   idx = torch.argsort(t, descending=descending, stable=True)[:n]
   mask = torch.zeros_like(t, dtype=torch.bool)
   mask[idx] = True

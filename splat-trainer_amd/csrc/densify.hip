@@ -1,0 +1,278 @@
+// Densify / prune support next to the path:
+//
+//   gsr_select_n ........ bool mask of the n smallest (or largest) of N floats, ties broken by ascending index -- the
+//                         deterministic form of the reference's take_n = argsort(t)[:n] -> mask
+//                         (splat_trainer/controller/target_controller.py:150-160), whose non-stable argsort leaves the
+//                         choice among equal values (0 and inf in their thousands: unseen points, min_views masking)
+//                         to the sort implementation.  4-pass 8-bit radix SELECT on order-preserving keys (no sort:
+//                         5 reads of the array instead of a full argsort), then the equal-to-threshold entries are
+//                         ranked in index order with a ballot prefix.
+//   gsr_compact_* ....... keep-mask stream compaction of ALL per-point columns at once (parameters, extras, optimizer
+//                         state) + append of the split children (scene.split_and_prune, scene/mlp_scene.py:301-310:
+//                         points[keep_mask] then append_tensors(splits)): per-block keep counts, one scan, then one
+//                         gather kernel that moves every column's kept rows to their final place, copies the appended
+//                         rows behind them and zero-fills the columns that have no appended data (new optimizer state).
+//
+// wave64 ballot / mbcnt ranks, LDS-staged row lists, integer atomics only (histogram counts): bit-reproducible.
+#include "gsr_device.h"
+#include "../../include/gsplat_hip.h"
+
+namespace {
+
+constexpr int DN_THREADS = 256;
+
+inline unsigned dn_grid(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// Order-preserving u32 key of a float: -0 folded onto +0 (equal under comparison), NaN above +inf (torch sorts it last).
+__device__ __forceinline__ uint32_t select_key(float v, bool descending) {
+  v = v + 0.0f;
+  if (v != v) v = __uint_as_float(0x7fc00000u);
+  const uint32_t b = __float_as_uint(v);
+  const uint32_t k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return descending ? ~k : k;
+}
+
+struct SelectState {      // device words shared by the passes
+  uint32_t prefix;        // decided high digits of the threshold key
+  uint32_t mask;          // which bits of `prefix` are decided
+  uint32_t remaining;     // how many entries are still to be taken inside the current prefix class
+  uint32_t pad;
+};
+
+__global__ __launch_bounds__(DN_THREADS) void select_hist_kernel(const float* __restrict__ values, int64_t N,
+                                                                 int descending, int shift,
+                                                                 const SelectState* __restrict__ st,
+                                                                 uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_hist[256];
+  s_hist[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t prefix = st->prefix, mask = st->mask;
+  for (int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x; i < N; i += (int64_t)gridDim.x * DN_THREADS) {
+    const uint32_t k = select_key(values[i], descending != 0);
+    if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = s_hist[threadIdx.x];
+  if (c) atomicAdd(&hist[threadIdx.x], c);
+}
+
+// One block: the digit whose bucket holds the `remaining`-th entry becomes part of the prefix; the histogram is cleared
+// for the next pass.
+__global__ __launch_bounds__(256) void select_pick_kernel(SelectState* __restrict__ st, uint32_t* __restrict__ hist,
+                                                          int shift) {
+  __shared__ uint32_t s_cum[256];
+  const int d = (int)threadIdx.x;
+  const uint32_t mine = hist[d];
+  hist[d] = 0u;
+  s_cum[d] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {                               // inclusive scan over the 256 digits
+    const uint32_t add = d >= o ? s_cum[d - o] : 0u;
+    __syncthreads();
+    s_cum[d] += add;
+    __syncthreads();
+  }
+  const uint32_t incl = s_cum[d], excl = incl - mine;
+  const uint32_t want = st->remaining;                              // 1-based rank inside the class
+  __syncthreads();
+  if (mine != 0u && excl < want && want <= incl) {                  // exactly one digit satisfies this
+    st->prefix |= (uint32_t)d << shift;
+    st->mask |= 255u << shift;
+    st->remaining = want - excl;
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void select_equal_count_kernel(const float* __restrict__ values, int64_t N,
+                                                                        int descending,
+                                                                        const SelectState* __restrict__ st,
+                                                                        uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t s_w[4];
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  const bool eq = i < N && select_key(values[i], descending != 0) == st->prefix;
+  const uint64_t b = __ballot(eq);
+  if (gsr_lane() == 0) s_w[threadIdx.x >> 6] = (uint32_t)__builtin_popcountll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(DN_THREADS) void select_mask_kernel(const float* __restrict__ values, int64_t N,
+                                                                 int descending, const SelectState* __restrict__ st,
+                                                                 const uint32_t* __restrict__ block_offsets,
+                                                                 uint8_t* __restrict__ mask_out) {
+  __shared__ uint32_t s_w[4];
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  const uint32_t thr = st->prefix, take = st->remaining;
+  const uint32_t k = i < N ? select_key(values[i], descending != 0) : 0xffffffffu;
+  const bool eq = i < N && k == thr;
+  const uint64_t b = __ballot(eq);
+  const int wave = threadIdx.x >> 6;
+  if (gsr_lane() == 0) s_w[wave] = (uint32_t)__builtin_popcountll(b);
+  __syncthreads();
+  uint32_t before = block_offsets[blockIdx.x] + (uint32_t)gsr_mbcnt(b);
+  for (int w = 0; w < wave; ++w) before += s_w[w];
+  if (i < N) mask_out[i] = (k < thr || (eq && before < take)) ? 1 : 0;   // equal entries: lowest indexes first
+}
+
+// ------------------------------------------------------------------------------------------------ compaction
+__global__ __launch_bounds__(DN_THREADS) void compact_count_kernel(const uint8_t* __restrict__ keep, int64_t N,
+                                                                   uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t s_w[4];
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  const uint64_t b = __ballot(i < N && keep[i] != 0);
+  if (gsr_lane() == 0) s_w[threadIdx.x >> 6] = (uint32_t)__builtin_popcountll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+struct ColumnSet {
+  GsrColumnC col[GSR_MAX_COLUMNS];
+  int n;
+};
+
+// Blocks [0, row_blocks): 256 source rows each -- kept rows ranked with ballot/mbcnt, their local ids staged in LDS,
+// then every column streams its kept rows to dst[offset + rank] (writes contiguous across the block).
+// Blocks [row_blocks, ...): 256 appended rows each -- copied from the column's tail, or zero-filled without one.
+__global__ __launch_bounds__(DN_THREADS) void compact_gather_kernel(const uint8_t* __restrict__ keep, int64_t N,
+                                                                    const uint32_t* __restrict__ block_offsets,
+                                                                    unsigned row_blocks, int64_t kept_total,
+                                                                    int64_t n_tail, ColumnSet cs) {
+  typedef uint32_t word;
+  if (blockIdx.x >= row_blocks) {
+    const int64_t r0 = (int64_t)(blockIdx.x - row_blocks) * DN_THREADS;
+    const int64_t rows = min((int64_t)DN_THREADS, n_tail - r0);
+    for (int c = 0; c < cs.n; ++c) {
+      const int w = cs.col[c].width_dwords;
+      word* dst = reinterpret_cast<word*>(cs.col[c].dst) + (kept_total + r0) * w;
+      const word* tail = reinterpret_cast<const word*>(cs.col[c].tail);
+      const int64_t total = rows * w;
+      if (tail) {
+        tail += r0 * w;
+        for (int64_t e = threadIdx.x; e < total; e += DN_THREADS) dst[e] = tail[e];
+      } else {
+        for (int64_t e = threadIdx.x; e < total; e += DN_THREADS) dst[e] = 0u;
+      }
+    }
+    return;
+  }
+  __shared__ uint32_t s_w[4];
+  __shared__ uint16_t s_src[DN_THREADS];
+  const int64_t row0 = (int64_t)blockIdx.x * DN_THREADS;
+  const int64_t i = row0 + threadIdx.x;
+  const bool k = i < N && keep[i] != 0;
+  const uint64_t b = __ballot(k);
+  const int wave = threadIdx.x >> 6;
+  if (gsr_lane() == 0) s_w[wave] = (uint32_t)__builtin_popcountll(b);
+  __syncthreads();
+  uint32_t rank = (uint32_t)gsr_mbcnt(b);
+  for (int w = 0; w < wave; ++w) rank += s_w[w];
+  const uint32_t kept = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  if (k) s_src[rank] = (uint16_t)threadIdx.x;
+  __syncthreads();
+  const int64_t base = block_offsets[blockIdx.x];
+  for (int c = 0; c < cs.n; ++c) {
+    const int w = cs.col[c].width_dwords;
+    const word* src = reinterpret_cast<const word*>(cs.col[c].src) + row0 * w;
+    word* dst = reinterpret_cast<word*>(cs.col[c].dst) + base * w;
+    const uint32_t total = kept * (uint32_t)w;
+    if (w == 1) {
+      for (uint32_t e = threadIdx.x; e < total; e += DN_THREADS) dst[e] = src[s_src[e]];
+    } else {
+      for (uint32_t e = threadIdx.x; e < total; e += DN_THREADS) {
+        const uint32_t r = e / (uint32_t)w, d = e - r * (uint32_t)w;
+        dst[e] = src[(uint32_t)s_src[r] * (uint32_t)w + d];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gsr_select_workspace_bytes(int64_t N) {
+  const size_t blocks = (size_t)((N > 0 ? N : 1) + DN_THREADS - 1) / DN_THREADS;
+  // state (16 B) + histogram (1 KiB) + block counts + the scan's own workspace
+  return 256 + 1024 + ((blocks * 4 + 255) / 256) * 256 + gsr_scan_workspace_bytes((int64_t)blocks);
+}
+
+int gsr_select_n(const float* values, int64_t N, int64_t n, int32_t descending, uint8_t* mask_out, void* workspace,
+                 size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || n < 0 || N >= (1ll << 32)) return GSR_ERR_INVALID_ARGUMENT;
+  if (N == 0) return GSR_OK;
+  if (!values || !mask_out) return GSR_ERR_INVALID_ARGUMENT;
+  if (n == 0 || n >= N) {
+    if (hipMemsetAsync(mask_out, n == 0 ? 0 : 1, (size_t)N, stream) != hipSuccess) return GSR_ERR_LAUNCH_FAILED;
+    return GSR_OK;
+  }
+  if (!workspace || workspace_bytes < gsr_select_workspace_bytes(N)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  uint8_t* ws = reinterpret_cast<uint8_t*>(workspace);
+  SelectState* st = reinterpret_cast<SelectState*>(ws);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(ws + 256);
+  uint32_t* block_counts = reinterpret_cast<uint32_t*>(ws + 256 + 1024);
+  const unsigned blocks = dn_grid(N, DN_THREADS);
+  uint8_t* scan_ws = ws + 256 + 1024 + (((size_t)blocks * 4 + 255) / 256) * 256;
+  const size_t scan_bytes = gsr_scan_workspace_bytes((int64_t)blocks);
+
+  if (hipMemsetAsync(ws, 0, 256 + 1024, stream) != hipSuccess) return GSR_ERR_LAUNCH_FAILED;
+  const uint32_t first = (uint32_t)n;
+  if (hipMemcpyAsync(&st->remaining, &first, sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess)
+    return GSR_ERR_LAUNCH_FAILED;
+  const unsigned hist_grid = blocks < 2048u ? blocks : 2048u;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    select_hist_kernel<<<hist_grid, DN_THREADS, 0, stream>>>(values, N, descending, shift, st, hist);
+    select_pick_kernel<<<1, 256, 0, stream>>>(st, hist, shift);
+  }
+  select_equal_count_kernel<<<blocks, DN_THREADS, 0, stream>>>(values, N, descending, st, block_counts);
+  GSR_CHECK_LAUNCH();
+  int rc = gsr_exclusive_scan_u32(block_counts, block_counts, (int64_t)blocks, nullptr, scan_ws, scan_bytes, stream_);
+  if (rc != GSR_OK) return rc;
+  select_mask_kernel<<<blocks, DN_THREADS, 0, stream>>>(values, N, descending, st, block_counts, mask_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+size_t gsr_compact_workspace_bytes(int64_t N) {
+  const size_t blocks = (size_t)((N > 0 ? N : 1) + DN_THREADS - 1) / DN_THREADS;
+  return ((blocks * 4 + 255) / 256) * 256 + gsr_scan_workspace_bytes((int64_t)blocks) + 256;
+}
+
+int gsr_compact_offsets(const uint8_t* keep_mask, int64_t N, uint32_t* block_offsets_out, uint32_t* kept_total_dev,
+                        void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || N >= (1ll << 32) || !kept_total_dev) return GSR_ERR_INVALID_ARGUMENT;
+  if (N == 0) {
+    if (hipMemsetAsync(kept_total_dev, 0, sizeof(uint32_t), stream) != hipSuccess) return GSR_ERR_LAUNCH_FAILED;
+    return GSR_OK;
+  }
+  if (!keep_mask || !block_offsets_out) return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned blocks = dn_grid(N, DN_THREADS);
+  if (!workspace || workspace_bytes < gsr_scan_workspace_bytes((int64_t)blocks)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  compact_count_kernel<<<blocks, DN_THREADS, 0, stream>>>(keep_mask, N, block_offsets_out);
+  GSR_CHECK_LAUNCH();
+  return gsr_exclusive_scan_u32(block_offsets_out, block_offsets_out, (int64_t)blocks, kept_total_dev, workspace,
+                                workspace_bytes, stream_);
+}
+
+int gsr_compact_columns(const uint8_t* keep_mask, int64_t N, const uint32_t* block_offsets, int64_t kept_total,
+                        int64_t n_tail, const GsrColumnC* columns_host, int32_t n_columns, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || kept_total < 0 || kept_total > N || n_tail < 0 || n_columns < 0 || n_columns > GSR_MAX_COLUMNS)
+    return GSR_ERR_INVALID_ARGUMENT;
+  if (n_columns == 0 || (N == 0 && n_tail == 0)) return GSR_OK;
+  if (!columns_host || (N > 0 && (!keep_mask || !block_offsets))) return GSR_ERR_INVALID_ARGUMENT;
+  ColumnSet cs;
+  cs.n = n_columns;
+  for (int c = 0; c < n_columns; ++c) {
+    cs.col[c] = columns_host[c];
+    if (cs.col[c].width_dwords <= 0 || !cs.col[c].dst || (N > 0 && !cs.col[c].src)) return GSR_ERR_INVALID_ARGUMENT;
+  }
+  const unsigned row_blocks = dn_grid(N, DN_THREADS), tail_blocks = dn_grid(n_tail, DN_THREADS);
+  if (row_blocks + tail_blocks == 0) return GSR_OK;
+  compact_gather_kernel<<<row_blocks + tail_blocks, DN_THREADS, 0, stream>>>(keep_mask, N, block_offsets, row_blocks,
+                                                                            kept_total, n_tail, cs);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""Densify / prune on the device: the two operations the reference's densification round
+spends its time in, as HIP kernels behind the C ABI (csrc/densify.hip).
+
+  select_n(values, n, descending) ... bool mask of the n smallest / largest entries, ties broken by ascending index --
+                                      deterministic replacement of ``take_n`` = ``argsort(t)[:n]`` -> mask
+                                      (splat_trainer/controller/target_controller.py:150-160)
+  compact_rows(keep_mask, columns) ... ``column[keep_mask]`` followed by ``cat(appended rows)`` for MANY columns in one
+                                      pass (scene.split_and_prune, splat_trainer/scene/mlp_scene.py:301-310)
+
+There is no CPU path: CUDA tensors and the HIP library are required.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+  return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def select_n(values: torch.Tensor, n: int, descending: bool = False) -> torch.Tensor:
+  """Bool mask with exactly ``min(n, N)`` entries set: the n smallest (``descending=False``) or largest values; among
+  equal values the lowest indexes win (a stable argsort's choice); NaN orders above +inf."""
+  lib = _lib.load()
+  if not values.is_cuda:
+    raise _lib.GsplatHipError("select_n runs only on a HIP device (got a CPU tensor); there is no CPU fallback")
+  if values.dim() != 1:
+    raise ValueError("select_n takes a 1-D tensor")
+  if n < 0:
+    raise ValueError(f"n must be >= 0, got {n}")
+  v = values.detach().to(torch.float32).contiguous()
+  N = v.shape[0]
+  mask = torch.empty(N, dtype=torch.bool, device=v.device)
+  if N == 0:
+    return mask
+  ws_bytes = lib.gsr_select_workspace_bytes(N)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=v.device)
+  _lib.check(lib.gsr_select_n(_p(v), N, int(n), 1 if descending else 0, _p(mask), _p(ws), ws_bytes, _stream()),
+             "gsr_select_n")
+  return mask
+
+
+def compact_rows(keep_mask: torch.Tensor, columns: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]],
+                 n_tail: Optional[int] = None) -> List[torch.Tensor]:
+  """For every ``(column, tail)``: ``cat([column[keep_mask], tail])`` -- ``tail = None`` appends ``n_tail`` zero rows.
+  All columns move in ONE gather launch (after one count + scan and one read-back of the kept count, which sizes the
+  outputs).  Columns are 4-byte-element tensors with N rows; a tail has the column's row shape."""
+  lib = _lib.load()
+  if not keep_mask.is_cuda or keep_mask.dtype != torch.bool or keep_mask.dim() != 1:
+    raise _lib.GsplatHipError("compact_rows needs a 1-D CUDA bool mask (no CPU fallback)")
+  N = keep_mask.shape[0]
+  dev = keep_mask.device
+  if n_tail is None:
+    tails = [t for _, t in columns if t is not None]
+    n_tail = int(tails[0].shape[0]) if tails else 0
+  cols = []
+  for col, tail in columns:
+    if not col.is_cuda or col.element_size() != 4 or col.shape[0] != N:
+      raise ValueError("columns must be CUDA tensors of 4-byte elements with one row per mask entry")
+    col = col.detach().contiguous()
+    if tail is not None:
+      if tuple(tail.shape[1:]) != tuple(col.shape[1:]) or tail.shape[0] != n_tail:
+        raise ValueError(f"tail of shape {tuple(tail.shape)} does not fit a column of row shape {tuple(col.shape[1:])}")
+      tail = tail.detach().to(col.dtype).contiguous()
+    cols.append((col, tail))
+  if len(cols) > _lib.MAX_COLUMNS:
+    raise ValueError(f"at most {_lib.MAX_COLUMNS} columns per call")
+  keep = keep_mask.contiguous()
+  blocks = max((N + 255) // 256, 1)
+  offsets = torch.empty(blocks, dtype=torch.int32, device=dev)
+  total = torch.empty(1, dtype=torch.int32, device=dev)
+  ws_bytes = lib.gsr_compact_workspace_bytes(N)
+  ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+  stream = _stream()
+  _lib.check(lib.gsr_compact_offsets(_p(keep), N, _p(offsets), _p(total), _p(ws), ws_bytes, stream),
+             "gsr_compact_offsets")
+  kept = int(total.item())                  # the one host sync: the outputs' size is data dependent
+  outs = [torch.empty((kept + n_tail,) + tuple(col.shape[1:]), dtype=col.dtype, device=dev) for col, _ in cols]
+  if kept + n_tail == 0 or not cols:
+    return outs
+  arr = (_lib.GsrColumnC * len(cols))()
+  for i, ((col, tail), out) in enumerate(zip(cols, outs)):
+    width = 1
+    for d in col.shape[1:]:
+      width *= int(d)
+    arr[i] = _lib.GsrColumnC(col.data_ptr() if N else None, out.data_ptr(),
+                             tail.data_ptr() if (tail is not None and n_tail) else None, max(width, 1))
+  _lib.check(lib.gsr_compact_columns(_p(keep), N, _p(offsets), kept, n_tail, arr, len(cols), stream),
+             "gsr_compact_columns")
+  return outs

@@ -208,29 +208,32 @@ class ParameterClass:
 
   @torch.no_grad()
   def keep_and_append(self, keep_mask: torch.Tensor, tensors: Dict[str, torch.Tensor]) -> "ParameterClass":
-    """``self[keep_mask].append_tensors(tensors)`` (mlp_scene.py:306-310) in one pass: the kept row indices are formed
-    once (one ``nonzero`` = one host sync instead of one per column), and every column -- parameters, extras and
-    optimizer state -- is written straight into its final buffer (one gather into the head, one copy or zero-fill of the
-    tail) instead of being masked into a temporary and concatenated."""
+    """``self[keep_mask].append_tensors(tensors)`` (mlp_scene.py:306-310) fused on the device (densify.compact_rows,
+    csrc/densify.hip): one ballot/prefix pass turns the mask into destination rows, then ONE gather launch moves every
+    column -- parameters, extras and optimizer state -- to its final buffer, copies the appended rows behind the kept
+    ones and zero-fills the appended rows of the optimizer state.  One host sync (the kept count sizes the buffers)."""
+    from .densify import compact_rows
     missing = set(self.tensors) - set(tensors)
     if missing:
       raise KeyError(f"keep_and_append: missing {sorted(missing)}")
-    keep_idx = keep_mask.nonzero().squeeze(1)
-    k, n_new = keep_idx.shape[0], next(iter(tensors.values())).shape[0]
-
-    def rebuilt(old: torch.Tensor, tail: Optional[torch.Tensor]) -> torch.Tensor:
-      out = torch.empty((k + n_new,) + tuple(old.shape[1:]), dtype=old.dtype, device=old.device)
-      torch.index_select(old.detach(), 0, keep_idx, out=out[:k])
-      if tail is None:
-        out[k:].zero_()
-      else:
-        out[k:].copy_(tail)
-      return out
-
+    n_new = next(iter(tensors.values())).shape[0]
     st = self._state
-    groups = {name: {n: rebuilt(v, None) for n, v in g.items()} for name, g in st["groups"].items()}
-    state = dict(step=rebuilt(st["step"], None), vis_avg=rebuilt(st["vis_avg"], None), groups=groups)
-    return self._like({name: rebuilt(t, tensors[name]) for name, t in self.tensors.items()}, state)
+    names = list(self.tensors)
+    columns = [(self.tensors[k], tensors[k]) for k in names]
+    state_cols = [("step", None, st["step"]), ("vis_avg", None, st["vis_avg"])]
+    for gname, g in st["groups"].items():
+      state_cols += [(gname, n, v) for n, v in g.items()]
+    columns += [(v, None) for _, _, v in state_cols]
+    outs = compact_rows(keep_mask, columns, n_tail=n_new)
+    new_tensors = dict(zip(names, outs[:len(names)]))
+    groups: Dict[str, Dict[str, torch.Tensor]] = {k: {} for k in st["groups"]}
+    state = dict(groups=groups)
+    for (gname, n, _), out in zip(state_cols, outs[len(names):]):
+      if n is None:
+        state[gname] = out
+      else:
+        groups[gname][n] = out
+    return self._like(new_tensors, state)
 
   def state_dict(self) -> dict:
     return dict(tensors={k: t.detach() for k, t in self.tensors.items()}, optimizer_state=self._state,

@@ -174,11 +174,12 @@ def main():
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--collective", default="auto", choices=["auto", "reduce_scatter", "all_reduce", "sh_factor"],
-                  help="auto (default) = sh_factor when WORLD_SIZE > 1, plain fused accumulation on one GPU; one fused all_reduce of the flat gradient buffer (default: RCCL spreads it over all xGMI links "
-                       "with several channels); reduce_scatter + all_gather of the same buffer; or sh_factor: all_reduce "
-                       "only the geometry gradients and all_gather the per-camera colour gradients (3 floats/splat), "
-                       "rebuilding the SH coefficient gradient (48 floats/splat) on every rank")
+  ap.add_argument("--collective", default="sh_factor", choices=["reduce_scatter", "all_reduce", "sh_factor"],
+                  help="gradient exchange at WORLD_SIZE > 1 (nothing is communicated on one GPU).  sh_factor (default, "
+                       "distributed.DEFAULT_COLLECTIVE): all_reduce only the geometry gradients and all_gather the "
+                       "per-camera colour gradients (3 floats/splat), rebuilding the SH coefficient gradient (48 "
+                       "floats/splat) on every rank; all_reduce: one fused all_reduce of the whole flat gradient buffer; "
+                       "reduce_scatter: reduce_scatter + all_gather of the same buffer")
   ap.add_argument("--check-collective", action="store_true",
                   help="after the timed run, do one step with all_reduce and one with --collective and report the "
                        "largest relative difference of the summed gradients (rehearsal aid; not timed)")
@@ -187,8 +188,6 @@ def main():
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
-  if args.collective == "auto":
-    args.collective = "sh_factor" if world > 1 else "all_reduce"
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if world != args.gpus and world > 1:
@@ -208,49 +207,38 @@ def main():
 
   import splat_trainer_amd as sta
   from splat_trainer_amd import renderer
-  from splat_trainer_amd.distributed import GradBucket, shard_cameras
+  from splat_trainer_amd.controller_math import PointState
+  from splat_trainer_amd.distributed import CameraShardedStep, GradBucket, replay_point_stats
 
   g, cams, w = make_workload(args.workload, world)
   cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True, blur_cov=0.3, antialias=False)
   N = g.position.shape[0]
   params = [t.to(dev).requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
   position, log_scaling, rotation, alpha_logit, feature = params
-  from splat_trainer_amd.distributed import exchange_sh_factors
   factor_mode = args.collective == "sh_factor"
-  # + the per-point `visible` accumulator (mlp_scene.py:244)
-  bucket = GradBucket(params[:4] if factor_mode else params, world, extra=N)
-  feature_grad = torch.empty_like(feature) if factor_mode else None
-  collector = sta.ShFactorCollector() if factor_mode else None
-  my_cams = [cams[j].to(dev) for j in shard_cameras(world, rank, world)]   # one camera per rank per step
+  # camera j of the batch -> rank j mod world; gradients accumulate straight into the flat collective buffer (the
+  # reference accumulates into .grad over the cameras of a batch, trainer.py:500-514); + the per-point `visible`
+  # accumulator (mlp_scene.py:244); the per-camera controller statistics of ALL cameras come back in camera order
+  dp = CameraShardedStep(params, world, rank, mode=args.collective)
+  bucket = dp.bucket
+  batch = [c.to(dev) for c in cams[:max(world, 1)]]                       # one camera per rank per step
   target_image = torch.full((w["h"], w["w"], 3), 0.5, device=dev)
   scene = sta.Gaussians3D(position=position, rotation=rotation, log_scaling=log_scaling, alpha_logit=alpha_logit,
                           feature=feature)
-  # gradients accumulate straight into the flat collective buffer (the reference accumulates into .grad over
-  # the cameras of a batch, trainer.py:500-514)
-  grad_out = sta.GradOut(position=bucket.views[0], log_scaling=bucket.views[1], rotation=bucket.views[2],
-                         alpha_logit=bucket.views[3], feature=None if factor_mode else bucket.views[4])
+  point_state = PointState.new_zeros(N, dev)                               # the controller's state (point_state.py:22-32)
   last = {}
 
+  def render_backward(j, cam, grad_out, collector):
+    with torch.enable_grad():
+      r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
+      loss = torch.nn.functional.mse_loss(r.image.clamp(0, 1), target_image)    # trainer.py:472-475
+      loss.backward()
+    last["r"] = r
+    return r
+
   def step():
-    if factor_mode:
-      bucket.zero()
-    else:                                     # the first SH backward of the step overwrites the feature gradient
-      bucket.zero(except_views=(4,))
-      grad_out.feature_uninitialized = True
-    for cam in my_cams:
-      with torch.enable_grad():
-        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
-        loss = torch.nn.functional.mse_loss(r.image.clamp(0, 1), target_image)    # trainer.py:472-475
-        loss.backward()
-      bucket.extra.index_add_(0, r.points.idx, r.points.visibility)
-      last["r"] = r
-    if factor_mode:
-      # geometry gradients + visible accumulator (11+1 floats/splat); in flight while the factors are scattered
-      pending = bucket.all_reduce(mode="all_reduce", async_op=True)
-      exchange_sh_factors(collector, list(range(len(my_cams))), len(my_cams), feature, position, feature_grad,
-                          bucket.views[0], accumulate=False, after=pending)  # the term of ALL cameras; d_sh overwritten
-    else:
-      bucket.all_reduce(mode=args.collective)
+    stats = dp.run(batch, render_backward)
+    replay_point_stats(point_state, stats)        # controller.add_rendering for every camera of the batch, in order
 
   def sync():
     torch.cuda.synchronize()
@@ -282,17 +270,12 @@ def main():
     elapsed = float(t.item())
 
   check = None
-  if args.check_collective and factor_mode:
+  if args.check_collective and factor_mode and world > 1:
     step()
-    got = [v.clone() for v in bucket.views[:4]] + [feature_grad.clone()]
-    ref_bucket = GradBucket(params, world, extra=N)
-    ref_out = sta.GradOut(*ref_bucket.views[:5])
-    for cam in my_cams:
-      with torch.enable_grad():
-        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=ref_out)
-        torch.nn.functional.mse_loss(r.image.clamp(0, 1), target_image).backward()
-    ref_bucket.all_reduce(mode="all_reduce")
-    check = max(float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(got, ref_bucket.views[:5]))
+    got = [v.clone() for v in dp.grads.values()]
+    ref = CameraShardedStep(params, world, rank, mode="all_reduce", with_stats=False)
+    ref.run(batch, render_backward)
+    check = max(float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(got, ref.grads.values()))
     bucket.attach()
 
   r = last["r"]
@@ -345,7 +328,7 @@ def main():
                        dict(line(alg_bytes_fwd, ms_fwd, traffic_of("K6")),
                             valu=valu_roofline("K6", "K6_fwd_C3_vis", pmc, ms_fwd, O) if pmc else None),
                    "whole step (cull -> project -> SH -> bin -> sort -> composite -> loss -> backward)":
-                       line(alg_bytes_step * len(my_cams), median_ms)}})
+                       line(alg_bytes_step, median_ms)}})
     out = {
         "metric": "fwd+bwd Gaussians/s", "value": value, "unit": "Gaussians/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "ms_per_step_median": median_ms,

@@ -399,8 +399,11 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
   }
 }
 
+#ifndef GSR_K7_WAVES
+#define GSR_K7_WAVES 6
+#endif
 template <int C>
-__global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restrict__ rec,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES, GSR_K7_WAVES))) void composite_bwd_kernel(const float* __restrict__ rec,
                                                            const uint32_t* __restrict__ sorted_rank,
                                                            const uint32_t* __restrict__ sorted_inst,
                                                            const float* __restrict__ pair_vis,

@@ -9,11 +9,15 @@ optimizer state) are fully replicated; a camera's render is not split across GPU
 Collective choice.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so what matters is that the
 message is ONE large contiguous buffer that RCCL can split over all links/channels at once, not many
 per-tensor calls each bound by launch latency: all gradients are packed into one contiguous fp32 buffer
-(padded to a multiple of world_size; 120 MB at 500k splats/SH3, 708 MB at 3M).  ``mode="all_reduce"``
-(default of bench.py) issues a single fused all-reduce; ``mode="reduce_scatter"`` issues
-``reduce_scatter_tensor`` + ``all_gather_into_tensor`` on the same buffer (the form a sharded optimizer
-step would slot between; gloo, used by the CPU tests, falls back to all_reduce).  Neither could be timed in
-this build environment (one GPU); both are kept selectable.
+(padded to a multiple of world_size; 120 MB at 500k splats/SH3, 708 MB at 3M).
+
+ONE default everywhere (``DEFAULT_COLLECTIVE = "sh_factor"``, used by bench.py and ``CameraShardedStep``): a fused
+all-reduce of the geometry gradients + visible accumulator (12 floats per splat), an all-gather of the per-camera
+colour-gradient factors (3 floats per visible splat) from which every rank rebuilds the SH coefficient gradient, and
+an all-gather of the per-camera controller statistics (5 floats per visible splat), both packed to the largest
+visible count of the batch.  ``"all_reduce"`` (the whole 59-float buffer in one fused all-reduce) and
+``"reduce_scatter"`` (``reduce_scatter_tensor`` + ``all_gather_into_tensor`` on the same buffer; gloo falls back to
+all_reduce) stay selectable for comparison.  None could be timed on xGMI in this build environment (one GPU).
 """
 from __future__ import annotations
 
@@ -21,6 +25,10 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+DEFAULT_COLLECTIVE = "sh_factor"
+STAT_FIELDS = ("screen_scale_max", "visibility", "split_score", "prune_cost")
 
 
 def shard_cameras(num_cameras: int, rank: int, world_size: int) -> List[int]:
@@ -88,7 +96,7 @@ class GradBucket:
 
 def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, sh_features: torch.Tensor,
                         positions: torch.Tensor, d_sh: torch.Tensor, d_pos: Optional[torch.Tensor], group=None,
-                        accumulate: bool = True, after=None):
+                        accumulate: bool = True, after=None, visible_max: Optional[int] = None):
   """All-gathers the colour-gradient factors recorded by a ``ShFactorCollector`` and adds the summed SH coefficient
   gradient of ALL cameras of the batch to ``d_sh`` (N,3,K) -- and the view-direction term to ``d_pos`` (N,3) -- on every
   rank.  ``d_sh`` / ``d_pos`` therefore must NOT be all-reduced afterwards.  ``accumulate=False``: ``d_sh`` is
@@ -107,7 +115,10 @@ def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank
   from . import _lib
   lib = _lib.load()
   N, _, K = sh_features.shape
-  block = gather_sh_factors(collector, camera_slots, cameras_per_rank, N, group=group)
+  if visible_max is not None and 4 * (visible_max + 1) >= 3 * (N + 1):
+    visible_max = None               # packed rows would not be smaller than the dense block
+  block = gather_sh_factors(collector, camera_slots, cameras_per_rank, N, group=group, device=positions.device,
+                            visible_max=visible_max)
   if after is not None:
     after.wait()                     # e.g. the asynchronous all-reduce that delivers d_pos
   stride = (N + 1) * 3
@@ -120,54 +131,156 @@ def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank
   collector.clear()
 
 
-def gather_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, num_points: int, group=None):
-  """The collective half of ``exchange_sh_factors``: scatters this rank's recorded colour gradients to dense rows and
-  all-gathers them in ONE collective.  Every camera slot is a (N+1, 3) block: rows 0..N-1 the colour gradient of the
-  scene rows (zero where the camera saw nothing), row N the camera position.  Returns the (ws * cameras_per_rank, N+1, 3)
-  block, rank-major, identical on every rank.  Pure torch + torch.distributed (works on gloo/CPU)."""
+def exchange_counts(local: Sequence[Sequence[int]], slots_per_rank: int, device, group=None) -> List[List[int]]:
+  """All-gathers a few integers per camera slot (e.g. camera index, visible count) and returns them for every slot of
+  every rank, rank-major, as host ints: the sizes the packed exchanges below are padded to.  One tiny collective and
+  one read-back per batch (the only host sync of the exchange); unused slots hold -1."""
+  width = len(local[0]) if local else 2
+  mine = torch.full((slots_per_rank, width), -1, dtype=torch.int64)
+  for s, row in enumerate(local):
+    mine[s] = torch.tensor(list(row), dtype=torch.int64)
+  ws = dist.get_world_size(group) if dist.is_initialized() else 1
+  if ws == 1:
+    return mine.tolist()
+  mine = mine.to(device)
+  out = torch.empty(ws * slots_per_rank, width, dtype=torch.int64, device=device)
+  dist.all_gather_into_tensor(out, mine, group=group)
+  return out.cpu().tolist()
+
+
+def gather_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: int, num_points: int, group=None,
+                      device=None, visible_max: Optional[int] = None):
+  """The collective half of ``exchange_sh_factors``: ONE all-gather carries every camera's colour gradients and camera
+  position.  Returns the dense (ws * cameras_per_rank, N+1, 3) block the rebuild kernel reads -- rows 0..N-1 the colour
+  gradient of the scene rows (zero where the camera saw nothing), row N the camera position -- rank-major, identical on
+  every rank.  Pure torch + torch.distributed (works on gloo/CPU).
+
+  ``visible_max`` = None: the dense block itself goes over the wire (12 (N+1) bytes per camera).  ``visible_max`` = the
+  largest visible count of the batch (from ``exchange_counts``): packed rows [index, r, g, b] padded to that count go
+  over the wire (16 (visible_max+1) bytes per camera) and every rank scatters them into the dense block -- the cheaper
+  form once the frustum cull removes more than a quarter of the scene.  ``device``: where the block lives (required
+  when this rank recorded no camera)."""
   if len(collector.items) != len(camera_slots):
     raise ValueError(f"{len(collector.items)} recorded cameras but {len(camera_slots)} slots")
   if len(collector.items) > cameras_per_rank:
     raise ValueError("more recorded cameras than cameras_per_rank")
-  dev = collector.items[0][1].device if collector.items else None
-  mine = torch.zeros(cameras_per_rank, num_points + 1, 3, dtype=torch.float32, device=dev)
-  for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
-    mine[slot].index_copy_(0, idx, dcol)
-    mine[slot, num_points].copy_(cam)
+  dev = device if device is not None else (collector.items[0][1].device if collector.items else None)
+  if dev is None:
+    raise ValueError("gather_sh_factors: pass device= (this rank recorded no camera to take it from)")
   ws = dist.get_world_size(group) if dist.is_initialized() else 1
+  N = num_points
+  if visible_max is None:
+    mine = torch.zeros(cameras_per_rank, N + 1, 3, dtype=torch.float32, device=dev)
+    for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
+      mine[slot].index_copy_(0, idx, dcol)
+      mine[slot, N].copy_(cam)
+    if ws == 1:
+      return mine
+    block = torch.empty(ws * cameras_per_rank, N + 1, 3, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(block, mine, group=group)
+    return block
+  # packed: field-major (4, visible_max + 1); entry 0 of every field is the header [count | camera x, y, z]
+  L = int(visible_max) + 1
+  mine = torch.zeros(cameras_per_rank, 4, L, dtype=torch.float32, device=dev)
+  for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
+    m = idx.shape[0]
+    if m > visible_max:
+      raise ValueError(f"camera with {m} visible rows but visible_max = {visible_max}")
+    head = torch.tensor([m], dtype=torch.int32, device=dev)
+    mine[slot, 0, :1] = head.view(torch.float32)
+    mine[slot, 0, 1:1 + m] = idx.to(torch.int32).view(torch.float32)
+    mine[slot, 1:, 0] = cam
+    mine[slot, 1:, 1:1 + m] = dcol.t()
   if ws == 1:
-    return mine
-  block = torch.empty(ws * cameras_per_rank, num_points + 1, 3, dtype=torch.float32, device=dev)
-  dist.all_gather_into_tensor(block, mine, group=group)
+    packed = mine
+  else:
+    packed = torch.empty(ws * cameras_per_rank, 4, L, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(packed, mine, group=group)
+  counts = packed[:, 0, 0].contiguous().view(torch.int32).tolist()      # host sync; tiny
+  block = torch.zeros(packed.shape[0], N + 1, 3, dtype=torch.float32, device=dev)
+  for c, m in enumerate(counts):
+    if m > 0:
+      rows = packed[c, 0, 1:1 + m].contiguous().view(torch.int32).long()
+      block[c].index_copy_(0, rows, packed[c, 1:, 1:1 + m].t())
+    block[c, N] = packed[c, 1:, 0]
   return block
 
 
-def gather_point_stats(local: List[dict], num_cameras: int, group=None) -> List[dict]:
-  """All-gathers the per-camera point statistics (idx, screen_scale_max, visibility, split_score,
-  prune_cost) and returns them for ALL cameras in camera order, identical on every rank.
+def gather_point_stats(local: List[dict], num_cameras: int, group=None, device=None,
+                       counts: Optional[List[List[int]]] = None) -> List[dict]:
+  """All-gathers the per-camera point statistics -- ``idx`` and the STAT_FIELDS (screen_scale_max, visibility,
+  split_score, prune_cost; a missing field counts as zeros) -- and returns them for ALL cameras in camera order,
+  identical on every rank, as tensors on ``device``.
 
-  PointState.add_rendering (controller/point_state.py:34-50) blends with exp_lerp, which depends on
-  the order cameras are applied; replaying in camera order on every rank keeps the controller state
-  bit-identical to the sequential loop.  ``local`` holds dicts with a ``camera`` key."""
-  if not dist.is_initialized() or dist.get_world_size(group) == 1:
+  PointState.add_rendering (controller/point_state.py:34-50) blends with exp_lerp, which depends on the order cameras
+  are applied; replaying in camera order on every rank keeps the controller state bit-identical to the sequential
+  loop.  ``local`` holds dicts with a ``camera`` key.  Everything stays on the device: one field-major block
+  (5, visible_max) per camera slot -- row index bits + the four statistics -- padded to the largest visible count of the
+  batch, ONE ``all_gather_into_tensor``; the counts come from ``exchange_counts`` (passed in when the caller already
+  has them, e.g. shared with the factor exchange)."""
+  ws = dist.get_world_size(group) if dist.is_initialized() else 1
+  if ws == 1:
     return sorted(local, key=lambda d: d["camera"])
-  ws = dist.get_world_size(group)
-  gathered: List[Optional[list]] = [None] * ws
-  cpu_local = [{k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in d.items()} for d in local]
-  dist.all_gather_object(gathered, cpu_local, group=group)
-  flat = [d for part in gathered for d in part]
-  flat.sort(key=lambda d: d["camera"])
-  assert [d["camera"] for d in flat] == list(range(num_cameras)), "camera shards do not partition the batch"
-  return flat
+  cpr = (num_cameras + ws - 1) // ws
+  if len(local) > cpr:
+    raise ValueError("more local cameras than ceil(num_cameras / world_size)")
+  dev = device if device is not None else (local[0]["idx"].device if local else None)
+  if dev is None:
+    raise ValueError("gather_point_stats: pass device= (this rank rendered no camera to take it from)")
+  if counts is None:
+    counts = exchange_counts([(d["camera"], d["idx"].shape[0]) for d in local], cpr, dev, group=group)
+  L = max(max(m for _, m in counts), 1)
+  mine = torch.zeros(cpr, 1 + len(STAT_FIELDS), L, dtype=torch.float32, device=dev)
+  for s, d in enumerate(local):
+    m = d["idx"].shape[0]
+    mine[s, 0, :m] = d["idx"].to(torch.int32).view(torch.float32)
+    for f, name in enumerate(STAT_FIELDS):
+      if d.get(name) is not None:
+        mine[s, 1 + f, :m] = d[name].detach().to(torch.float32)
+  block = torch.empty(ws * cpr, 1 + len(STAT_FIELDS), L, dtype=torch.float32, device=dev)
+  dist.all_gather_into_tensor(block, mine, group=group)
+  out = []
+  for s, (cam, m) in enumerate(counts):
+    if cam < 0:
+      continue
+    d = dict(camera=int(cam), idx=block[s, 0, :m].view(torch.int32).long())
+    for f, name in enumerate(STAT_FIELDS):
+      d[name] = block[s, 1 + f, :m]
+    out.append(d)
+  out.sort(key=lambda d: d["camera"])
+  assert [d["camera"] for d in out] == list(range(num_cameras)), "camera shards do not partition the batch"
+  return out
+
+
+def point_stats_of(camera: int, points) -> dict:
+  """The statistics of one rendered camera the controller consumes (point_state.py:34-50), read AFTER backward."""
+  return dict(camera=camera, idx=points.idx, screen_scale_max=points.screen_scale.max(1).values,
+              visibility=points.visibility, split_score=points.split_score, prune_cost=points.prune_cost)
+
+
+def replay_point_stats(state, stats: Sequence[dict]):
+  """Applies the gathered statistics to a controller_math.PointState in camera order -- the reference's own
+  per-camera ``add_rendering`` arithmetic, run on every rank for every camera of the batch."""
+  from .data_types import RenderedPoints, Rendering
+  for d in stats:
+    m = d["idx"].shape[0]
+    z = torch.zeros(m, dtype=torch.float32, device=d["idx"].device)
+    scale = d["screen_scale_max"] if d.get("screen_scale_max") is not None else z
+    pts = RenderedPoints(idx=d["idx"], depths=z[:, None], opacity=z, screen_scale=torch.stack([scale, scale], dim=1),
+                         visibility=d["visibility"], prune_cost=d["prune_cost"] if d.get("prune_cost") is not None else z,
+                         split_score=d["split_score"] if d.get("split_score") is not None else z)
+    state.add_rendering(Rendering(image=None, camera=None, points=pts))
+  return state
 
 
 def evaluate_backward_sharded(params: Sequence[torch.Tensor], cameras: Sequence, render_loss_fn: Callable,
-                              bucket: Optional[GradBucket] = None, group=None, mode: str = "reduce_scatter"):
+                              bucket: Optional[GradBucket] = None, group=None, mode: str = "all_reduce", device=None):
   """Multi-GPU form of trainer.py:500-514.  Each rank renders + backprops its cameras
   (``render_loss_fn(camera_index, camera) -> (loss, stats_dict)`` must call ``loss.backward()`` itself or
   return a loss to be backpropagated here), gradients accumulate across the rank's cameras exactly as
   in the reference (no zeroing between cameras), then ONE fused collective sums them over ranks.
-  Returns the per-camera stats of the whole batch in camera order."""
+  Returns the per-camera stats of the whole batch in camera order.  This is the generic form (any render function,
+  whole-buffer collective); ``CameraShardedStep`` is the product path with the factor exchange."""
   rank = dist.get_rank(group) if dist.is_initialized() else 0
   ws = dist.get_world_size(group) if dist.is_initialized() else 1
   local_stats = []
@@ -185,4 +298,74 @@ def evaluate_backward_sharded(params: Sequence[torch.Tensor], cameras: Sequence,
     for p in params:
       if p.grad is not None:
         dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group)
-  return gather_point_stats(local_stats, len(cameras), group=group)
+  dev = device if device is not None else (params[0].device if len(params) else None)
+  return gather_point_stats(local_stats, len(cameras), group=group, device=dev)
+
+
+class CameraShardedStep:
+  """One data-parallel batch of the hot path, the way bench.py and the tests run it: this rank renders and
+  back-propagates ITS cameras of the batch (camera j -> rank j mod world) with the gradients accumulating straight into
+  one flat buffer, then the default exchange (``DEFAULT_COLLECTIVE``) delivers on every rank the summed gradients of all
+  cameras and -- in camera order -- the per-camera controller statistics.  With one rank nothing is communicated.
+
+      step = CameraShardedStep(params, world, rank)          # params: position, log_scaling, rotation, alpha_logit, feature
+      stats = step.run(cameras, render_backward)              # render_backward(j, camera, grad_out, sh_collector) -> Rendering
+      step.grads                                              # name -> summed gradient tensor
+  """
+  NAMES = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
+
+  def __init__(self, params: Sequence[torch.Tensor], world_size: int, rank: int, group=None,
+               mode: str = DEFAULT_COLLECTIVE, with_stats: bool = True):
+    from .renderer import GradOut
+    from .sh import ShFactorCollector
+    self.params = list(params)
+    self.world, self.rank, self.group, self.mode, self.with_stats = max(world_size, 1), rank, group, mode, with_stats
+    self.factor = mode == "sh_factor" and self.world > 1
+    N = self.params[0].shape[0]
+    self.bucket = GradBucket(self.params[:4] if self.factor else self.params, self.world, extra=N)
+    self.feature_grad = torch.empty_like(self.params[4]) if self.factor else None
+    self.collector = ShFactorCollector() if self.factor else None
+    v = self.bucket.views
+    self.grad_out = GradOut(position=v[0], log_scaling=v[1], rotation=v[2], alpha_logit=v[3],
+                            feature=None if self.factor else v[4])
+
+  @property
+  def grads(self) -> dict:
+    v = self.bucket.views
+    return dict(zip(self.NAMES, list(v[:4]) + [self.feature_grad if self.factor else v[4]]))
+
+  @property
+  def visible(self) -> torch.Tensor:
+    return self.bucket.extra
+
+  def run(self, cameras: Sequence, render_backward: Callable) -> List[dict]:
+    position, feature = self.params[0], self.params[4]
+    dev = position.device
+    mine = shard_cameras(len(cameras), self.rank, self.world)
+    if self.factor:
+      self.bucket.zero()
+    else:                                     # the first SH backward of the batch overwrites the feature gradient
+      self.bucket.zero(except_views=(4,))
+      self.grad_out.feature_uninitialized = True
+    local = []
+    for j in mine:
+      r = render_backward(j, cameras[j], self.grad_out, self.collector)
+      self.bucket.extra.index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
+      if self.with_stats:
+        local.append(point_stats_of(j, r.points))
+    if self.world == 1:
+      return local
+    cpr = (len(cameras) + self.world - 1) // self.world
+    counts = exchange_counts([(d["camera"], d["idx"].shape[0]) for d in local] if self.with_stats else
+                             [(j, it[0].shape[0]) for j, it in zip(mine, self.collector.items)] if self.factor else
+                             [(j, 0) for j in mine], cpr, dev, group=self.group)
+    if self.factor:
+      pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True)
+      exchange_sh_factors(self.collector, list(range(len(mine))), cpr, feature, position, self.feature_grad,
+                          self.bucket.views[0], group=self.group, accumulate=False, after=pending,
+                          visible_max=max(m for _, m in counts))
+    else:
+      self.bucket.all_reduce(group=self.group, mode=self.mode)
+    if not self.with_stats:
+      return []
+    return gather_point_stats(local, len(cameras), group=self.group, device=dev, counts=counts)

@@ -100,6 +100,55 @@ def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=Fals
               num_overlaps=out.num_overlaps)
 
 
+def oracle_render_and_grads_chunked(g, cam, config, use_sh, target=0.5, dtype=torch.float64, loss_scale=1.0,
+                                    chunk_tiles=1024):
+  """Same outputs as oracle_render_and_grads for FULL-SIZE scenes: the composite stage runs tile chunk by tile chunk with
+  a backward per chunk (the MSE is a sum over pixels), so the autograd graph of only one chunk is alive at a time; the
+  per-point heuristics come from a second, gradient-free pass per chunk fed with that chunk's image gradient."""
+  leaves = [t.clone().to(dtype).requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+  pos, ls, rot, al, feat = leaves
+  T, proj = cam.T_camera_world.to(dtype), cam.projection.to(dtype)
+  W, H = cam.image_size
+  idx = oracle.frustum_cull(pos, T, proj, cam.image_size, cam.near_plane, cam.far_plane,
+                            config.margin_tiles * config.tile_size)
+  g2d, depth, sscale = oracle.project(pos, ls, rot, al, idx, T, proj, config)
+  if use_sh:
+    R = T[:3, :3]
+    feats = oracle.evaluate_sh_at(feat, pos, idx, -(R.t() @ T[:3, 3]))
+  else:
+    feats = feat[idx]
+  g2d_d, feats_d = g2d.detach().requires_grad_(True), feats.detach().requires_grad_(True)
+  lists = oracle._tile_lists(g2d_d, depth.detach(), cam.image_size, config)
+  n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+  C = feats.shape[1]
+  M = idx.shape[0]
+  image = torch.zeros(H, W, C, dtype=dtype)
+  final_T = torch.ones(H, W, dtype=dtype)
+  vis, prune, split = (torch.zeros(M, dtype=dtype) for _ in range(3))
+  overlaps = 0
+  for t0 in range(0, n_tiles, chunk_tiles):
+    tiles = torch.arange(t0, min(t0 + chunk_tiles, n_tiles))
+    out = oracle.rasterize(g2d_d, depth.detach(), feats_d, cam.image_size, config, tiles=tiles, lists=lists)
+    img = out.image
+    img.retain_grad()
+    loss = ((img.clamp(0, 1) - target) ** 2).sum() / (W * H * C) * loss_scale
+    # pixels outside this chunk are constant zeros in `img`: they add a constant to the loss and nothing to any gradient
+    loss.backward()
+    with torch.no_grad():
+      heur = oracle.rasterize(g2d_d.detach(), depth.detach(), feats_d.detach(), cam.image_size, config, tiles=tiles,
+                              lists=lists, dL_dimage=img.grad)
+      image += out.image.detach()
+      final_T = torch.minimum(final_T, out.final_T)
+      vis += out.visibility
+      prune += heur.prune_cost
+      split += heur.split_score
+    overlaps = out.num_overlaps
+  torch.autograd.backward([g2d, feats], [g2d_d.grad, feats_d.grad])
+  return dict(image=image, final_T=final_T, visibility=vis, g2d=g2d.detach(), d_g2d=g2d_d.grad, depth=depth.detach(),
+              screen_scale=sscale, idx=idx, d_position=pos.grad, d_log_scaling=ls.grad, d_rotation=rot.grad,
+              d_alpha_logit=al.grad, d_feature=feat.grad, prune_cost=prune, split_score=split, num_overlaps=overlaps)
+
+
 def hip_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, device="cuda", loss_scale=1.0):
   import splat_trainer_amd as sta
   gd = sta.Gaussians3D(*(t.clone().to(device).requires_grad_(True) for t in

@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_path):
   bucket = GradBucket(params, world)
   assert shard_cameras(len(cams), rank, world) == [j for j in range(len(cams)) if j % world == rank]
   stats = evaluate_backward_sharded(params, cams, lambda j, cam: _render_loss(params, cam, cfg), bucket=bucket,
-                                    mode="reduce_scatter")      # gloo falls back to all_reduce
+                                    mode="reduce_scatter", device="cpu")      # gloo falls back to all_reduce
   assert [s["camera"] for s in stats] == list(range(len(cams)))
   torch.save(dict(grads=[p.grad.clone() for p in params], vis=[s["visibility"] for s in stats],
                   idx=[s["idx"] for s in stats]), f"{out_path}.{rank}")
@@ -145,3 +145,75 @@ def test_two_rank_sh_factor_gather_rebuilds_the_summed_sh_gradient(tmp_path):
     col = oracle.evaluate_sh_at(sh, g.position, idx, cams[j].camera_position)
     col.backward(dcol)
   assert torch.allclose(r0["d_sh"], sh.grad, rtol=1e-4, atol=1e-6)
+
+
+def _stats_worker(rank, world, port, out_path, num_cameras):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from splat_trainer_amd.controller_math import PointState, find_split_prune_indexes
+  from splat_trainer_amd.distributed import (exchange_counts, gather_point_stats, gather_sh_factors, replay_point_stats,
+                                             shard_cameras)
+  from splat_trainer_amd.sh import ShFactorCollector
+  n = 500
+  mine = shard_cameras(num_cameras, rank, world)
+  cpr = (num_cameras + world - 1) // world
+  local = [_camera_stats(j, n) for j in mine]
+  got = gather_point_stats(local, num_cameras, device="cpu")                    # rank 1 may hold no camera at all
+  state = replay_point_stats(PointState.new_zeros(n, "cpu"), got)
+  masks = find_split_prune_indexes(state, 0.2, 560, min_views=1, max_scale_px=50.0)
+  # the factor gather, dense and packed, with the same counts
+  col = ShFactorCollector()
+  for j in mine:
+    d = _camera_stats(j, n)
+    col.items.append((d["idx"], d["dcol"], d["cam"]))
+  counts = exchange_counts([(j, it[0].shape[0]) for j, it in zip(mine, col.items)], cpr, "cpu")
+  dense = gather_sh_factors(col, list(range(len(mine))), cpr, n, device="cpu")
+  packed = gather_sh_factors(col, list(range(len(mine))), cpr, n, device="cpu", visible_max=max(m for _, m in counts))
+  fields = ("prune_cost", "split_score", "max_scale_px", "points_in_view", "visibility")
+  torch.save(dict(stats=got, masks=masks, state={f: getattr(state, f) for f in fields}, dense=dense, packed=packed,
+                  counts=counts), f"{out_path}.{rank}")
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _camera_stats(j, n):
+  gen = torch.Generator().manual_seed(100 + j)
+  m = n // 2 + 17 * j                                           # cameras see different numbers of points
+  idx = torch.randperm(n, generator=gen)[:m].sort().values
+  vis = torch.rand(m, generator=gen)
+  vis[torch.rand(m, generator=gen) < 0.2] = 0.0
+  return dict(camera=j, idx=idx, screen_scale_max=40 * torch.rand(m, generator=gen) + 1, visibility=vis,
+              split_score=torch.rand(m, generator=gen) * (vis > 0), prune_cost=torch.rand(m, generator=gen) * (vis > 0),
+              dcol=torch.randn(m, 3, generator=gen), cam=torch.randn(3, generator=gen))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("num_cameras", [1, 3, 4])
+def test_two_rank_point_stats_and_packed_factors(tmp_path, num_cameras):
+  """distributed.gather_point_stats over gloo (one packed all_gather_into_tensor + counts; with 1 or 3 cameras a rank
+  holds an empty slot or no camera at all): every rank receives every camera's statistics unchanged and in camera order,
+  the PointState replayed from them -- and the split/prune masks -- equal the sequential loop's bit for bit, and the
+  packed colour-factor gather scatters to exactly the dense block."""
+  from splat_trainer_amd.controller_math import PointState, find_split_prune_indexes
+  from splat_trainer_amd.distributed import STAT_FIELDS, replay_point_stats
+  world, port = 2, 33000 + (os.getpid() % 2000) + num_cameras
+  out = str(tmp_path / "stats")
+  mp.spawn(_stats_worker, args=(world, port, out, num_cameras), nprocs=world, join=True)
+  r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+  n = 500
+  seq = [_camera_stats(j, n) for j in range(num_cameras)]
+  for r in (r0, r1):
+    assert [d["camera"] for d in r["stats"]] == list(range(num_cameras))
+    for d, want in zip(r["stats"], seq):
+      assert torch.equal(d["idx"], want["idx"])
+      for f in STAT_FIELDS:
+        assert torch.equal(d[f], want[f]), f
+    assert torch.equal(r["dense"], r["packed"])
+  state = replay_point_stats(PointState.new_zeros(n, "cpu"), seq)            # the sequential loop (trainer.py:500-514)
+  masks = find_split_prune_indexes(state, 0.2, 560, min_views=1, max_scale_px=50.0)
+  for r in (r0, r1):
+    for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view", "visibility"):
+      assert torch.equal(r["state"][f], getattr(state, f)), f
+    assert torch.equal(r["masks"][0], masks[0]) and torch.equal(r["masks"][1], masks[1])
+  if num_cameras > 1:
+    assert masks[0].any() and masks[1].any()

@@ -120,11 +120,18 @@ def test_keep_and_append_equals_mask_then_append_and_times_3m():
         assert torch.equal(fused._state["groups"][g][name], two_step._state["groups"][g][name]), (g, name)
     assert torch.equal(fused._state["step"], two_step._state["step"])
     assert torch.equal(fused._state["vis_avg"], two_step._state["vis_avg"])
-    t0 = time.perf_counter()
-    ref_take = torch.argsort(state.prune_cost, stable=True)[: n // 40]
-    torch.cuda.synchronize()
-    t_argsort = time.perf_counter() - t0
-    print(f"densify round at {label}: masks (2 radix selects + mask ops) {t_select * 1e3:.2f} ms "
-          f"[one torch stable argsort alone: {t_argsort * 1e3:.2f} ms]; keep+append of "
+    def timed(fn, reps=5):
+      fn()
+      torch.cuda.synchronize()
+      t = time.perf_counter()
+      for _ in range(reps):
+        fn()
+      torch.cuda.synchronize()
+      return (time.perf_counter() - t) / reps
+    pc_, _ = state.masked_heuristics(5)
+    t_sel = timed(lambda: densify.select_n(pc_, n // 40))
+    t_argsort = timed(lambda: _reference_mask(pc_, n // 40, False))
+    print(f"densify round at {label}: find_split_prune_indexes {t_select * 1e3:.2f} ms (first call); one take_n: radix "
+          f"select {t_sel * 1e3:.3f} ms vs torch stable argsort + mask {t_argsort * 1e3:.3f} ms; keep+append of "
           f"{len(pc.keys()) + 2 + 2 * len(pc._state['groups'])} columns fused {t_fused * 1e3:.2f} ms vs mask-then-append "
           f"{t_torch * 1e3:.2f} ms; {n} -> {fused.num_points} points")

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import splat_trainer_amd as sta
-from helpers import compare_to_oracle, frac_above, hip_render_and_grads, oracle, oracle_render_and_grads, rel_err, small_scene
+from helpers import compare_to_oracle, frac_above, hip_render_and_grads, observe, oracle_render_and_grads_chunked, oracle, oracle_render_and_grads, rel_err, small_scene
 from splat_trainer_amd import synthetic
 from splat_trainer_amd.controller_math import PointState, find_split_prune_indexes
 
@@ -164,7 +164,7 @@ def test_full_size_properties_config2(n, w, h):
   """BASELINE.json configs[1] (500k, 1080p, SH3).  Size-independent properties:
      (1) unit features: image + final_T == 1 at every pixel (the weights partition unity);
      (2) d(sum image)/d feature_i == visibility_i (both are sum_px T alpha, one via backward, one via forward);
-     (3) two runs are bit-identical;  (4) a 64-tile sample equals the oracle."""
+     (3) two runs are bit-identical.  (The oracle comparison at this size is the next test.)"""
   g, cam = synthetic.scene_a(n, w, h, sh_degree=3, seed=0)
   camd = cam.to("cuda")
   gd = sta.Gaussians3D(*(t.cuda() for t in (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
@@ -181,20 +181,53 @@ def test_full_size_properties_config2(n, w, h):
   b = hip_render_and_grads(g, cam, cfg, use_sh=True)
   for k in ("image", "visibility", "prune_cost", "split_score", "d_position", "d_feature"):
     assert torch.equal(a[k], b[k]), k
-  # oracle on a fixed 64-tile sample
-  feats = sta.evaluate_sh_at(gd.feature, gd.position, idx, camd.camera_position)
-  tiles_x = (w + 15) // 16
-  gen = torch.Generator().manual_seed(0)
-  tiles = torch.randperm(tiles_x * ((h + 15) // 16), generator=gen)[:64]
-  out = oracle.rasterize(g2d.detach().cpu(), depth.detach().cpu(), feats.detach().cpu(), (w, h), cfg, tiles=tiles)
-  img = a["image"].cpu()
-  for t in tiles.tolist():
-    ty, tx = t // tiles_x, t % tiles_x
-    ys, xs = slice(ty * 16, min(ty * 16 + 16, h)), slice(tx * 16, min(tx * 16 + 16, w))
-    assert (img[ys, xs] - out.image[ys, xs]).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("n,w,h,deg", [(3_000_000, 1920, 1080, 3), (10_000_000, 3840, 2160, 1)])
+def _masks_from(res, n, target_points, t=0.3, min_views=2, max_scale_px=200.0, views=3):
+  """The reference's controller maths (PointState EMA over a few views + take_n; point_state.py:34-57,
+  target_controller.py:73-96) on one result dict, on the CPU (stable argsort)."""
+  st = PointState.new_zeros(n, "cpu")
+  M = res["idx"].shape[0]
+  pts = sta.RenderedPoints(idx=res["idx"].cpu(), depths=res["depth"].cpu().float(), opacity=torch.zeros(M),
+                           screen_scale=res["screen_scale"].cpu().float(), visibility=res["visibility"].cpu().float(),
+                           prune_cost=res["prune_cost"].cpu().float(), split_score=res["split_score"].cpu().float())
+  for _ in range(views):
+    st.add_rendering(sta.Rendering(image=None, camera=None, points=pts))
+  split, prune = find_split_prune_indexes(st, t=t, target_points=target_points, min_views=min_views,
+                                          max_scale_px=max_scale_px)
+  return split, prune, st
+
+
+def test_config2_full_size_matches_oracle_everywhere():
+  """BASELINE.json configs[1] at FULL size (500k Gaussians, 1920x1080, SH degree 3): image, final T, all five parameter
+  gradients, visibility / prune_cost / split_score of every point against the fp64 oracle (composited chunk by chunk on
+  the host cores), and the densification masks the reference's controller maths derives from both.  A mask may differ
+  from the oracle's only at points whose score lies within 2e-5 (relative) of the selection threshold -- two fp32 sums
+  that close cannot be ordered by any implementation; the count is logged."""
+  n, w, h = 500_000, 1920, 1080
+  g, cam = synthetic.scene_a(n, w, h, sh_degree=3, seed=0)
+  scale = float(w * h * 3)                      # SUM loss: keeps the heuristics well inside fp32's normal range
+  hip = hip_render_and_grads(g, cam, CFG, use_sh=True, loss_scale=scale)
+  orc = oracle_render_and_grads_chunked(g, cam, CFG, use_sh=True, loss_scale=scale)
+  assert 0 < hip["num_overlaps"] <= orc["num_overlaps"]      # the oracle bins by bounding box, K4 by the exact ellipse
+  compare_to_oracle("c2 full size 500k 1080p SH3", hip, orc, TOL)
+  mse = ((hip["image"].cpu().double() - orc["image"]) ** 2).mean().item()
+  assert mse < 1e-12, mse                       # PSNR vs oracle > 120 dB
+  hs, hp, hst = _masks_from(hip, n, int(1.1 * n))
+  os_, op, ost = _masks_from(orc, n, int(1.1 * n))
+  assert hs.sum() > 10_000 and hp.sum() > 5_000
+  # threshold of each selection in the oracle's scores: smallest selected split score / largest selected prune cost
+  for name, hm, om, score, thr in (("split", hs, os_, ost.split_score, ost.split_score[os_].min()),
+                                   ("prune", hp, op, ost.prune_cost, ost.prune_cost[op].max())):
+    diff = (hm ^ om).nonzero().squeeze(1)
+    observe("c2 full size masks", f"{name}_mask", hm.float(), om.float(), 0.5)
+    if diff.numel():
+      rel = ((score[diff] - thr).abs() / thr.abs().clamp_min(1e-30)).max().item()
+      assert rel < 2e-5, (name, diff.numel(), rel)
+    assert diff.numel() <= 20, (name, diff.numel())
+
+
+@pytest.mark.parametrize("n,w,h,deg", [(3_000_000, 1920, 1080, 3), (10_000_000, 3840, 2160, 3)])
 def test_full_size_properties_large_configs(n, w, h, deg):
   """BASELINE.json configs[2] / configs[4] sizes (3M at 1080p; 10M at 4K with the frustum cull active), one camera.
   Properties that need no oracle:

@@ -72,3 +72,37 @@ def test_config_c4_scaled_100_iterations():
   assert log.num_points[0] == 200_000 and tr.num_points == 220_000          # reaches the controller's target
   assert all(torch.isfinite(p).all() for p in tr.params.values())
   assert log.losses[-1] < log.losses[0]
+
+
+def test_config_c4_full_size_3m_100_iterations_reproducible_masks():
+  """BASELINE config c4 at its stated size: 3M Gaussians (Scene B), 1920x1080, SH degree 3, 100 iterations of an
+  8-camera batch, sparse visibility-aware LaProp step, TargetController densify/prune every 25
+  iterations towards 3.3M points (device radix-select masks + fused compaction).  Run twice: the loss curve, the point
+  counts and the sha256 digests of the split/prune masks of all three densify rounds must be identical."""
+  import time
+  n, w, h = 3_000_000, 1920, 1080
+  g, cams = synthetic.scene_b(n, w, h, sh_degree=3, seed=1, num_cameras=8)
+  dev = "cuda"
+  g = g.to(dev)
+  cams = [c.to(dev) for c in cams]
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  targets = [torch.full((h, w, 3), 0.5, device=dev) for _ in cams]
+  logs = []
+  for run in range(2):
+    tr = MiniTrainer(g, cams, targets, cfg, lr=1e-3, densify_every=25, target_points=3_300_000, prune_rate=0.025,
+                     min_views=5, total_steps=100, seed=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    log = tr.train(100)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"c4 full size, run {run}: {100 / dt:.1f} it/s ({1e3 * dt / 100:.1f} ms per 8-camera iteration), N {log.num_points[0]} -> "
+          f"{tr.num_points}, masks {[d[:12] for d in log.mask_digests]}, peak {torch.cuda.max_memory_allocated() / 1e9:.1f} GB",
+          flush=True)
+    assert len(log.mask_digests) == 3 and len(set(log.mask_digests)) == 3
+    assert log.num_points[0] == n and tr.num_points == 3_300_000
+    assert all(torch.isfinite(p).all() for p in tr.params.values())
+    assert log.losses[-1] < log.losses[0]
+    logs.append((log.mask_digests, log.losses, log.num_points))
+    del tr
+  assert logs[0] == logs[1]

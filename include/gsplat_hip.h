@@ -70,7 +70,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 12) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 13) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -166,7 +166,8 @@ int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, u
  * into ceil(len / seg_pairs) segments that are composited and back-propagated by one wave each.
  * gsr_segment_capacity: host-side bound on the number of segments of a frame with O overlaps (sizes the buffers). */
 int64_t gsr_segment_capacity(int64_t O, int32_t seg_pairs, int32_t heavy_min);
-/* tile_seg_out [num_tiles,2], seg_desc_out [capacity,4], seg_total_out [1] (see GsrSegmentsC). */
+/* tile_seg_out [num_tiles,2], seg_desc_out [capacity,4], seg_total_out [1] (see GsrSegmentsC); seg_total_out must be
+ * ZERO on entry (tiles reserve their segment slots with an integer atomic on it). */
 int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs, int32_t heavy_min,
                      int64_t capacity, uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out,
                      void* stream);
@@ -256,6 +257,16 @@ int gsr_compact_offsets(const uint8_t* keep_mask, int64_t N, uint32_t* block_off
 /* One launch moves every column: kept rows to dst[0, kept), tail rows (or zeros) to dst[kept, kept + n_tail). */
 int gsr_compact_columns(const uint8_t* keep_mask, int64_t N, const uint32_t* block_offsets, int64_t kept_total,
                         int64_t n_tail, const GsrColumnC* columns_host, int32_t n_columns, void* stream);
+
+/* PointState.add_rendering (splat_trainer/controller/point_state.py:34-50) for one camera, fused: for every row m of
+ * the camera's list, with i = idx[m]:  max_scale_px[i] = max(., max over the scale_cols (1 or 2) columns of
+ * screen_scale[m]);  points_in_view[i] += visibility[m] > 0;  visibility[i] += visibility[m];
+ * split_score[i] = exp_lerp(split_alpha, ., split_score[m]);  prune_cost[i] = exp_lerp(prune_alpha, ., prune_cost[m]).
+ * idx rows are unique (one camera); the state arrays have N entries (points_in_view int16). */
+int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t scale_cols, const float* visibility,
+                        const float* split_score, const float* prune_cost, int64_t M, float split_alpha,
+                        float prune_alpha, float* state_prune_cost, float* state_split_score, float* state_max_scale_px,
+                        int16_t* state_points_in_view, float* state_visibility, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class GsrRasterParamsC(C.Structure):
@@ -83,6 +83,7 @@ PROTOTYPES = {
     "gsr_compact_workspace_bytes": (_sz, [_i64]),
     "gsr_compact_offsets": (C.c_int, [_p, _i64, _p, _p, _p, _sz, _p]),
     "gsr_compact_columns": (C.c_int, [_p, _i64, _p, _i64, _i64, C.POINTER(GsrColumnC), _i32, _p]),
+    "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
 }

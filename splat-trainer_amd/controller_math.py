@@ -37,7 +37,13 @@ class PointState:
     return PointState(z(), z(), z(), z(torch.int16), z())
 
   def add_rendering(self, rendering, split_alpha: float = 0.01, prune_alpha: float = 0.1):
+    """point_state.py:34-50.  On the device the five updates run as one fused launch (densify.point_state_add); on the
+    CPU (the oracle side of the mask-parity tests) as the reference's torch ops below."""
     points = rendering.points
+    if self.prune_cost.is_cuda:
+      from .densify import point_state_add
+      point_state_add(self, points, split_alpha, prune_alpha)
+      return
     image_scale_px = points.screen_scale.max(1).values
     self.max_scale_px[points.idx] = torch.maximum(self.max_scale_px[points.idx], image_scale_px)
     self.points_in_view[points.visible.idx] += 1

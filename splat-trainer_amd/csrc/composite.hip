@@ -255,7 +255,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
                                                            float* __restrict__ pair_vis, SegDev seg) {
   if ((int)blockIdx.x >= num_tiles) {                                // extra blocks: pass A of the heavy tiles
     const uint32_t sidx = blockIdx.x - (uint32_t)num_tiles;
-    if (sidx < seg.seg_total[0]) seg_alpha_pass<C>(sidx, rec, sorted_rank, tiles_x, rp, seg);
+    if (sidx < seg.seg_total[0] && seg.seg_desc[4 * (size_t)sidx + 1] < seg.seg_desc[4 * (size_t)sidx + 2])
+      seg_alpha_pass<C>(sidx, rec, sorted_rank, tiles_x, rp, seg);
     return;
   }
   const int tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
@@ -591,49 +592,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
   }
 }
 
-// One block plans the whole frame: a tile with more than `heavy_min` pairs is cut into ceil(len / seg_pairs) segments of
-// (almost) equal length; segments are numbered tile by tile in tile order.
-__global__ __launch_bounds__(1024) void segment_plan_kernel(const uint32_t* __restrict__ tile_range, int num_tiles,
-                                                            uint32_t seg_pairs, uint32_t heavy_min, uint32_t capacity,
-                                                            uint32_t* __restrict__ tile_seg,
-                                                            uint32_t* __restrict__ seg_desc,
-                                                            uint32_t* __restrict__ seg_total) {
-  __shared__ uint32_t s_sum[1024];
-  const int tid = (int)threadIdx.x;
-  const int per = (num_tiles + 1023) / 1024;
-  const int t0 = min(tid * per, num_tiles), t1 = min(t0 + per, num_tiles);
-  auto nseg = [&](int t) -> uint32_t {
-    const uint32_t len = tile_range[2 * t + 1] - tile_range[2 * t];
-    return len > heavy_min ? (len + seg_pairs - 1) / seg_pairs : 0u;
-  };
-  uint32_t mine = 0;
-  for (int t = t0; t < t1; ++t) mine += nseg(t);
-  s_sum[tid] = mine;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {                               // inclusive scan of the per-thread counts
-    const uint32_t add = tid >= o ? s_sum[tid - o] : 0u;
-    __syncthreads();
-    s_sum[tid] += add;
-    __syncthreads();
-  }
-  uint32_t at = s_sum[tid] - mine;
-  const uint32_t total = s_sum[1023];
-  if (tid == 0) seg_total[0] = total <= capacity ? total : 0u;        // cannot exceed the bound the host sized for
-  for (int t = t0; t < t1; ++t) {
-    const uint32_t n = total <= capacity ? nseg(t) : 0u;
-    tile_seg[2 * t] = at;
-    tile_seg[2 * t + 1] = n;
-    if (n) {
-      const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
-      const uint32_t base = len / n, rem = len % n;
-      uint32_t b = a;
-      for (uint32_t j = 0; j < n; ++j) {
-        const uint32_t e = b + base + (j < rem ? 1u : 0u);
-        uint32_t* d = seg_desc + 4 * (size_t)(at + j);
-        d[0] = (uint32_t)t; d[1] = b; d[2] = e; d[3] = j;
-        b = e;
+// Plans the frame, one thread per tile: a tile with more than `heavy_min` pairs is cut into ceil(len / seg_pairs)
+// segments of (almost) equal length, numbered consecutively from a slot range the tile reserves with one integer atomic
+// on the (zero-initialised) segment counter.  Which range a tile gets depends on arrival order; nothing else does: a
+// tile's segments are contiguous and in list order, and every result is a function of that order alone.
+__global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __restrict__ tile_range, int num_tiles,
+                                                           uint32_t seg_pairs, uint32_t heavy_min, uint32_t capacity,
+                                                           uint32_t* __restrict__ tile_seg,
+                                                           uint32_t* __restrict__ seg_desc,
+                                                           uint32_t* __restrict__ seg_total) {
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= num_tiles) return;
+  const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
+  uint32_t n = len > heavy_min ? (len + seg_pairs - 1) / seg_pairs : 0u;
+  uint32_t at = 0u;
+  if (n) {
+    at = atomicAdd(seg_total, n);
+    if (at + n > capacity) {                       // cannot happen with the host's bound; stay in range regardless:
+      for (uint32_t j = at; j < capacity; ++j) {   // the tile stays light and its reserved slots become empty segments
+        uint32_t* d = seg_desc + 4 * (size_t)j;
+        d[0] = (uint32_t)t; d[1] = a; d[2] = a; d[3] = 0u;
       }
-      at += n;
+      n = 0u;
+    }
+  }
+  tile_seg[2 * t] = at;
+  tile_seg[2 * t + 1] = n;
+  if (n) {
+    const uint32_t base = len / n, rem = len % n;
+    uint32_t b = a;
+    for (uint32_t j = 0; j < n; ++j) {
+      const uint32_t e = b + base + (j < rem ? 1u : 0u);
+      uint32_t* d = seg_desc + 4 * (size_t)(at + j);
+      d[0] = (uint32_t)t; d[1] = b; d[2] = e; d[3] = j;
+      b = e;
     }
   }
 }
@@ -674,8 +666,9 @@ int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_
   if (num_tiles <= 0 || seg_pairs <= 0 || heavy_min < seg_pairs || capacity <= 0 || capacity > 0x7fffffffll)
     return GSR_ERR_INVALID_ARGUMENT;
   if (!tile_range || !tile_seg_out || !seg_desc_out || !seg_total_out) return GSR_ERR_INVALID_ARGUMENT;
-  segment_plan_kernel<<<1, 1024, 0, stream>>>(tile_range, num_tiles, (uint32_t)seg_pairs, (uint32_t)heavy_min,
-                                             (uint32_t)capacity, tile_seg_out, seg_desc_out, seg_total_out);
+  segment_plan_kernel<<<(num_tiles + 255) / 256, 256, 0, stream>>>(tile_range, num_tiles, (uint32_t)seg_pairs,
+                                                                  (uint32_t)heavy_min, (uint32_t)capacity, tile_seg_out,
+                                                                  seg_desc_out, seg_total_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

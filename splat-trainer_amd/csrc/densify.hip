@@ -13,6 +13,12 @@
 //                         gather kernel that moves every column's kept rows to their final place, copies the appended
 //                         rows behind them and zero-fills the columns that have no appended data (new optimizer state).
 //
+//   gsr_point_state_add . the controller's per-camera statistics update PointState.add_rendering
+//                         (splat_trainer/controller/point_state.py:34-50: max / += / count / two exp_lerp EMAs over the
+//                         rows a camera saw) as ONE launch instead of ~15 gather / scatter launches: it runs once per
+//                         camera inside the training step, and once per camera of the WHOLE batch on every rank of a
+//                         data-parallel job (the EMAs are order dependent, so every rank replays every camera).
+//
 // wave64 ballot / mbcnt ranks, LDS-staged row lists, integer atomics only (histogram counts): bit-reproducible.
 #include "gsr_device.h"
 #include "../../include/gsplat_hip.h"
@@ -185,9 +191,57 @@ __global__ __launch_bounds__(DN_THREADS) void compact_gather_kernel(const uint8_
   }
 }
 
+// exp_lerp(t, a, b) = max + log(lerp(exp(a - max), exp(b - max), t))   (splat_trainer/util/misc.py:57-59)
+__device__ __forceinline__ float exp_lerp(float t, float a, float b) {
+  const float m = fmaxf(a, b);
+  const float ea = expf(a - m), eb = expf(b - m);
+  return m + logf(ea + t * (eb - ea));
+}
+
+__global__ __launch_bounds__(DN_THREADS) void point_state_add_kernel(const int64_t* __restrict__ idx,
+                                                                     const float* __restrict__ scale, int scale_cols,
+                                                                     const float* __restrict__ vis,
+                                                                     const float* __restrict__ split,
+                                                                     const float* __restrict__ prune, int64_t M,
+                                                                     float split_alpha, float prune_alpha,
+                                                                     float* __restrict__ st_prune,
+                                                                     float* __restrict__ st_split,
+                                                                     float* __restrict__ st_scale,
+                                                                     int16_t* __restrict__ st_views,
+                                                                     float* __restrict__ st_vis) {
+  const int64_t m = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (m >= M) return;
+  const int64_t i = idx[m];                       // rows of one camera are unique: no two threads share a point
+  float sc = scale[m * scale_cols];
+  if (scale_cols == 2) sc = fmaxf(sc, scale[m * 2 + 1]);
+  const float v = vis[m];
+  st_scale[i] = fmaxf(st_scale[i], sc);
+  if (v > 0.f) st_views[i] = (int16_t)(st_views[i] + 1);
+  st_vis[i] += v;
+  st_split[i] = exp_lerp(split_alpha, st_split[i], split[m]);
+  st_prune[i] = exp_lerp(prune_alpha, st_prune[i], prune[m]);
+}
+
 }  // namespace
 
 extern "C" {
+
+int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t scale_cols, const float* visibility,
+                        const float* split_score, const float* prune_cost, int64_t M, float split_alpha,
+                        float prune_alpha, float* state_prune_cost, float* state_split_score, float* state_max_scale_px,
+                        int16_t* state_points_in_view, float* state_visibility, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || (scale_cols != 1 && scale_cols != 2)) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!idx || !screen_scale || !visibility || !split_score || !prune_cost || !state_prune_cost || !state_split_score ||
+      !state_max_scale_px || !state_points_in_view || !state_visibility)
+    return GSR_ERR_INVALID_ARGUMENT;
+  point_state_add_kernel<<<dn_grid(M, DN_THREADS), DN_THREADS, 0, stream>>>(
+      idx, screen_scale, scale_cols, visibility, split_score, prune_cost, M, split_alpha, prune_alpha, state_prune_cost,
+      state_split_score, state_max_scale_px, state_points_in_view, state_visibility);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
 
 size_t gsr_select_workspace_bytes(int64_t N) {
   const size_t blocks = (size_t)((N > 0 ? N : 1) + DN_THREADS - 1) / DN_THREADS;

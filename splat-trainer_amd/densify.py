@@ -97,3 +97,27 @@ def compact_rows(keep_mask: torch.Tensor, columns: Sequence[Tuple[torch.Tensor, 
   _lib.check(lib.gsr_compact_columns(_p(keep), N, _p(offsets), kept, n_tail, arr, len(cols), stream),
              "gsr_compact_columns")
   return outs
+
+
+def point_state_add(state, points, split_alpha: float = 0.01, prune_alpha: float = 0.1):
+  """``PointState.add_rendering`` (splat_trainer/controller/point_state.py:34-50) for one camera in one launch, in place
+  on the state's device tensors.  ``points``: RenderedPoints (idx, screen_scale (M,2) or (M,), visibility, split_score,
+  prune_cost)."""
+  lib = _lib.load()
+  idx = points.idx.contiguous()
+  M = idx.shape[0]
+  if M == 0:
+    return state
+  f32 = lambda t: t.detach().to(torch.float32).contiguous()
+  scale = f32(points.screen_scale)
+  cols = 2 if scale.dim() == 2 else 1
+  for t in (state.prune_cost, state.split_score, state.max_scale_px, state.visibility):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+      raise _lib.GsplatHipError("point_state_add needs contiguous float32 CUDA state tensors (no CPU fallback)")
+  if state.points_in_view.dtype != torch.int16:
+    raise ValueError("points_in_view must be int16 (point_state.py:27)")
+  _lib.check(lib.gsr_point_state_add(_p(idx), _p(scale), cols, _p(f32(points.visibility)), _p(f32(points.split_score)),
+                                     _p(f32(points.prune_cost)), M, float(split_alpha), float(prune_alpha),
+                                     _p(state.prune_cost), _p(state.split_score), _p(state.max_scale_px),
+                                     _p(state.points_in_view), _p(state.visibility), _stream()), "gsr_point_state_add")
+  return state

@@ -266,7 +266,8 @@ def replay_point_stats(state, stats: Sequence[dict]):
     m = d["idx"].shape[0]
     z = torch.zeros(m, dtype=torch.float32, device=d["idx"].device)
     scale = d["screen_scale_max"] if d.get("screen_scale_max") is not None else z
-    pts = RenderedPoints(idx=d["idx"], depths=z[:, None], opacity=z, screen_scale=torch.stack([scale, scale], dim=1),
+    pts = RenderedPoints(idx=d["idx"], depths=z[:, None], opacity=z,
+                         screen_scale=scale if scale.is_cuda else torch.stack([scale, scale], dim=1),
                          visibility=d["visibility"], prune_cost=d["prune_cost"] if d.get("prune_cost") is not None else z,
                          split_score=d["split_score"] if d.get("split_score") is not None else z)
     state.add_rendering(Rendering(image=None, camera=None, points=pts))

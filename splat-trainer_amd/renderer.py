@@ -243,10 +243,11 @@ def _launch_depth_order(depth: torch.Tensor, M: int) -> torch.Tensor:
   return vals_b if where == 1 else vals_a
 
 
-def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream):
+def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream, seg_total: torch.Tensor):
   """Heavy-tile list segmentation (composite.hip): tiles with more than ``segment_min_pairs`` pairs are cut into
   segments of at most ``segment_pairs``; returns the GsrSegmentsC the composite calls take, or None when switched off.
-  The tables are sized from a host-side bound on the segment count, so no extra sync is needed."""
+  The tables are sized from a host-side bound on the segment count, so no extra sync is needed.  ``seg_total``: a
+  zero-initialised device word (the plan kernel's tiles reserve their segment slots on it)."""
   st.segment_buffers = None
   if st.seg_pairs <= 0:
     return None
@@ -254,8 +255,8 @@ def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream):
   cap = int(lib.gsr_segment_capacity(O, st.seg_pairs, st.seg_min))
   if cap <= 0:
     return None
-  tables = torch.empty(2 * num_tiles + 4 * cap + 1, dtype=torch.int32, device=dev)
-  tile_seg, seg_desc, seg_total = tables[:2 * num_tiles], tables[2 * num_tiles:2 * num_tiles + 4 * cap], tables[-1:]
+  tables = torch.empty(2 * num_tiles + 4 * cap, dtype=torch.int32, device=dev)
+  tile_seg, seg_desc = tables[:2 * num_tiles], tables[2 * num_tiles:]
   _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, st.seg_pairs, st.seg_min, cap, _ptr(tile_seg),
                                   _ptr(seg_desc), _ptr(seg_total), stream), "gsr_segment_plan")
   planes = 2 + st.C + (1 if st.want_median else 0)
@@ -263,7 +264,7 @@ def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream):
   seg_last = torch.empty(cap * 256, dtype=torch.int32, device=dev)
   seg_P, seg_T, seg_C = pix[:cap * 256], pix[cap * 256:2 * cap * 256], pix[2 * cap * 256:(2 + st.C) * cap * 256]
   seg_med = pix[(2 + st.C) * cap * 256:] if st.want_median else None
-  st.segment_buffers = (tables, pix, seg_last)                      # kept alive until backward has run
+  st.segment_buffers = (tables, pix, seg_last, seg_total)           # kept alive until backward has run
   return _lib.GsrSegmentsC(tile_seg.data_ptr(), seg_desc.data_ptr(), seg_total.data_ptr(), cap, seg_P.data_ptr(),
                            seg_T.data_ptr(), seg_C.data_ptr(), seg_last.data_ptr(),
                            seg_med.data_ptr() if seg_med is not None else None)
@@ -329,7 +330,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   tkeys_b, tvals_a, tvals_b, trank_b = _u32(O, dev), _u32(O, dev), _u32(O, dev), _u32(O, dev)
   # everything that must start at zero comes out of ONE zero-filled allocation (one fill launch instead of three)
   n_vis = O if need_vis_partial else 0
-  zeros = torch.zeros(2 * M + 2 * num_tiles + n_vis, dtype=torch.float32, device=dev)
+  zeros = torch.zeros(2 * M + 2 * num_tiles + 1 + n_vis, dtype=torch.float32, device=dev)
   heuristics(zeros[:2 * M].view(2, M))
   # K6 writes every pixel of every tile (an empty tile writes colour 0, T 1, last 0): no zero-fills needed
   image = torch.empty(H, W, C_, dtype=torch.float32, device=dev)
@@ -350,9 +351,10 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   st.tile_range = zeros[2 * M:2 * M + 2 * num_tiles].view(torch.int32).view(num_tiles, 2)
   _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), O, num_tiles, _ptr(st.tile_range), stream), "gsr_tile_ranges")
 
-  st.vis_partial = zeros[2 * M + 2 * num_tiles:] if need_vis_partial else None
+  st.vis_partial = zeros[2 * M + 2 * num_tiles + 1:] if need_vis_partial else None
   st.pair_vis = torch.empty(O, dtype=torch.float32, device=dev) if need_vis_partial else None
-  st.segments = _plan_segments(st, num_tiles, O, dev, stream)
+  st.segments = _plan_segments(st, num_tiles, O, dev, stream,
+                               zeros[2 * M + 2 * num_tiles:2 * M + 2 * num_tiles + 1].view(torch.int32))
   timer = KERNEL_TIMER
   if timer is not None:
     timer.begin("composite_forward")

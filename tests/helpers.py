@@ -48,19 +48,23 @@ GRAD_KEYS = ("d_position", "d_log_scaling", "d_rotation", "d_alpha_logit", "d_fe
 POINT_KEYS = ("visibility", "prune_cost", "split_score", "screen_scale", "depth")
 
 
-def compare_to_oracle(label: str, hip: dict, orc: dict, tol: float = 1e-4, pixel_flips: float = 5e-5,
-                      point_flips: float = 5e-4, worst_pixel: float = 0.02, worst_point: float = 5e-3,
+def compare_to_oracle(label: str, hip: dict, orc: dict, tol: float = 1e-4, pixel_flips: float = 0.0,
+                      point_flips: float = 0.0, worst_pixel: float = 0.0, worst_point: float = 0.0,
                       keys=("image", "final_T") + POINT_KEYS + GRAD_KEYS):
-  """HIP vs oracle at ``tol`` relative to each tensor's max magnitude.  A pixel lying within fp32 rounding of a discrete
-  contribute/skip boundary (q = 9, alpha = 1/255, T = 1e-4) may take the other branch than the fp64 oracle; the share
-  of such entries is bounded by ``pixel_flips`` (images) / ``point_flips`` (per-point sums and gradients, which a
-  flipped pixel also moves) and their size by ``worst_*``.  Every observed number is logged (PARITY_LOG)."""
+  """HIP vs oracle: EVERY entry within ``tol`` of the oracle, relative to the tensor's max magnitude (BASELINE.json's
+  1e-4 criterion) -- the default, and what all scenes up to tens of thousands of splats satisfy with two orders of
+  margin (observed max 3e-6, profiles/r02_parity_observed.txt).
+
+  Only the full-size scenes pass allowances: among 6e7 contributing (pixel, splat) pairs a few dozen lie within fp32
+  rounding of a discrete contribute/skip boundary (q = 9, alpha = 1/255, T = 1e-4) and take the other branch than the
+  fp64 oracle.  ``pixel_flips`` / ``point_flips`` bound the SHARE of entries above ``tol`` (images / per-point sums and
+  gradients, which a flipped pixel also moves), ``worst_*`` their size.  Every observed number is logged (PARITY_LOG)."""
   assert torch.equal(hip["idx"].cpu(), orc["idx"])
   for k in keys:
     image_like = k in ("image", "final_T", "median")
     worst, frac = observe(label, k, hip[k], orc[k], tol)
     assert frac <= (pixel_flips if image_like else point_flips), (label, k, frac, worst)
-    assert worst < (worst_pixel if image_like else worst_point), (label, k, worst)
+    assert worst < max(tol, worst_pixel if image_like else worst_point), (label, k, worst)
 
 
 def small_scene(n=400, w=64, h=48, sh_degree=0, seed=3, sigma_px=3.0):

@@ -135,3 +135,30 @@ def test_keep_and_append_equals_mask_then_append_and_times_3m():
           f"select {t_sel * 1e3:.3f} ms vs torch stable argsort + mask {t_argsort * 1e3:.3f} ms; keep+append of "
           f"{len(pc.keys()) + 2 + 2 * len(pc._state['groups'])} columns fused {t_fused * 1e3:.2f} ms vs mask-then-append "
           f"{t_torch * 1e3:.2f} ms; {n} -> {fused.num_points} points")
+
+
+def test_point_state_add_matches_the_reference_arithmetic():
+  """gsr_point_state_add vs PointState.add_rendering's torch ops (point_state.py:34-50, run on the CPU) over a few
+  cameras: max / count / sum exact, the two exp_lerp EMAs to 1e-6 (expf / logf of the device vs the host)."""
+  import splat_trainer_amd as sta
+  gen = torch.Generator().manual_seed(9)
+  n = 50_000
+  dev_state, cpu_state = PointState.new_zeros(n, DEV), PointState.new_zeros(n, "cpu")
+  for cam in range(4):
+    m = 30_000 + 1000 * cam
+    idx = torch.randperm(n, generator=gen)[:m].sort().values
+    vis = torch.rand(m, generator=gen)
+    vis[torch.rand(m, generator=gen) < 0.3] = 0.0
+    pts = sta.RenderedPoints(idx=idx, depths=torch.zeros(m, 1), opacity=torch.zeros(m),
+                             screen_scale=50 * torch.rand(m, 2, generator=gen), visibility=vis,
+                             prune_cost=torch.rand(m, generator=gen) * 10 ** (4 * torch.rand(m, generator=gen) - 2) * (vis > 0),
+                             split_score=torch.rand(m, generator=gen) * (vis > 0))
+    cpu_state.add_rendering(sta.Rendering(image=None, camera=None, points=pts))
+    dev_pts = sta.RenderedPoints(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in vars(pts).items()})
+    dev_state.add_rendering(sta.Rendering(image=None, camera=None, points=dev_pts))
+  assert torch.equal(dev_state.max_scale_px.cpu(), cpu_state.max_scale_px)
+  assert torch.equal(dev_state.points_in_view.cpu(), cpu_state.points_in_view)
+  assert torch.allclose(dev_state.visibility.cpu(), cpu_state.visibility, rtol=1e-6, atol=0)
+  for f in ("split_score", "prune_cost"):
+    a, b = getattr(dev_state, f).cpu(), getattr(cpu_state, f)
+    assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (f, (a - b).abs().max().item())

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 import splat_trainer_amd as sta
-from helpers import frac_above, hip_render_and_grads, oracle_render_and_grads, rel_err
+from helpers import hip_render_and_grads, observe, oracle_render_and_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -60,12 +60,14 @@ def test_random_scene_matches_oracle(seed):
   # scenes of test_gpu_render.py.
   tol = 1e-3
   for k in ("image", "final_T"):
-    assert frac_above(hip[k], orc[k], tol) <= 1e-2, (seed, k, frac_above(hip[k], orc[k], tol))
-    assert rel_err(hip[k], orc[k]) < 0.03, (seed, k)
+    worst, frac = observe(f"fuzz seed {seed}", k, hip[k], orc[k], tol)
+    assert frac <= 1e-2, (seed, k, frac)
+    assert worst < 0.03, (seed, k, worst)
   for k in ("visibility", "prune_cost", "split_score", "screen_scale", "depth", "d_position", "d_log_scaling",
             "d_rotation", "d_alpha_logit", "d_feature"):
     if orc[k].abs().max() == 0:
       assert hip[k].abs().max() == 0, (seed, k)
       continue
-    assert frac_above(hip[k], orc[k], tol) <= 1e-2, (seed, k, frac_above(hip[k], orc[k], tol), rel_err(hip[k], orc[k]))
-    assert rel_err(hip[k], orc[k]) < 3e-2, (seed, k, rel_err(hip[k], orc[k]))
+    worst, frac = observe(f"fuzz seed {seed}", k, hip[k], orc[k], tol)
+    assert frac <= 1e-2, (seed, k, frac, worst)
+    assert worst < 3e-2, (seed, k, worst)

@@ -77,6 +77,10 @@ const char* gsr_error_string(int code);
 size_t gsr_scan_workspace_bytes(int64_t n);
 int gsr_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_dev, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Same scan with an overflow guard: *overflow_dev (zero on entry) is set to 1 when a prefix or the total reaches 2^31
+ * (beyond what the 32-bit list positions downstream can address; also raised before any u32 wrap can occur). */
+int gsr_exclusive_scan_u32_checked(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_dev,
+                                   uint32_t* overflow_dev, void* workspace, size_t workspace_bytes, void* stream);
 size_t gsr_sort_workspace_bytes(int64_t n);
 /* Stable LSD radix sort of (key, value) pairs by key bits [begin_bit, end_bit); ping-pongs a<->b.
  * Returns 0 if the result ends in (keys_a, vals_a), 1 if in (keys_b, vals_b), negative on error. */

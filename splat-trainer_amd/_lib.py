@@ -53,6 +53,7 @@ PROTOTYPES = {
     "gsr_error_string": (C.c_char_p, [C.c_int]),
     "gsr_scan_workspace_bytes": (_sz, [_i64]),
     "gsr_exclusive_scan_u32": (C.c_int, [_p, _p, _i64, _p, _p, _sz, _p]),
+    "gsr_exclusive_scan_u32_checked": (C.c_int, [_p, _p, _i64, _p, _p, _p, _sz, _p]),
     "gsr_sort_workspace_bytes": (_sz, [_i64]),
     "gsr_sort_pairs_u32": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p]),
     "gsr_sort_pairs2_u32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p]),

@@ -34,37 +34,57 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* total_
   return base + incl - v;
 }
 
+// Overflow guard of the u32 scans: every kernel that forms a sum also forms it in float (range, not precision) and
+// raises *overflow when prefix + total reaches 2^31 -- sums the 32-bit index arithmetic downstream cannot hold anyway.
+// A u32 wrap is always preceded by such a crossing, at whichever level of the scan it happens.
+__device__ __forceinline__ void flag_if_large(float mine, uint32_t prefix, uint32_t* overflow) {
+  __shared__ float s_f[4];
+  const float w = gsr_wave_sum(mine);
+  if (gsr_lane() == 0) s_f[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0 && (float)prefix + ((s_f[0] + s_f[1]) + (s_f[2] + s_f[3])) >= 2147000000.f) *overflow = 1u;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n,
-                                                                   uint32_t* __restrict__ block_sums) {
+                                                                   uint32_t* __restrict__ block_sums,
+                                                                   uint32_t* __restrict__ overflow) {
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   uint32_t sum = 0;
+  float fsum = 0.f;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     uint32_t idx = base + i;
-    sum += (idx < n) ? in[idx] : 0u;
+    const uint32_t v = (idx < n) ? in[idx] : 0u;
+    sum += v;
+    fsum += (float)v;
   }
   uint32_t total;
   block_scan_excl(sum, &total);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  if (overflow) flag_if_large(fsum, 0u, overflow);
 }
 
 // out[i] = block_offsets[b] + exclusive prefix inside the block.  block_offsets may be null (single block).
 // The grand total (sum of everything) is written to *total_out by the last block when total_out != null.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* in, uint32_t n,   // in may alias out
                                                                   const uint32_t* __restrict__ block_offsets,
-                                                                  uint32_t* out, uint32_t* __restrict__ total_out) {
+                                                                  uint32_t* out, uint32_t* __restrict__ total_out,
+                                                                  uint32_t* __restrict__ overflow) {
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
   uint32_t sum = 0;
+  float fsum = 0.f;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     uint32_t idx = base + i;
     v[i] = (idx < n) ? in[idx] : 0u;
     sum += v[i];
+    fsum += (float)v[i];
   }
   uint32_t total;
   uint32_t excl = block_scan_excl(sum, &total);
   uint32_t boff = block_offsets ? block_offsets[blockIdx.x] : 0u;
+  if (overflow) flag_if_large(fsum, boff, overflow);
   uint32_t run = boff + excl;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
@@ -86,24 +106,25 @@ size_t scan_ws_bytes(uint64_t n) {
   return bytes + 256;
 }
 
-int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, uint8_t* ws, hipStream_t stream) {
+int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev, uint8_t* ws, hipStream_t stream,
+              uint32_t* overflow = nullptr) {
   if (n == 0) {
     if (total_dev) hipMemsetAsync(total_dev, 0, sizeof(uint32_t), stream);
     return GSR_OK;
   }
   uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
   if (nb == 1) {
-    scan_apply_kernel<<<1, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, nullptr, out, total_dev);
+    scan_apply_kernel<<<1, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, nullptr, out, total_dev, overflow);
     GSR_CHECK_LAUNCH();
     return GSR_OK;
   }
   uint32_t* block_sums = reinterpret_cast<uint32_t*>(ws);
   size_t used = (((size_t)nb * sizeof(uint32_t) + 255) / 256) * 256;
-  scan_reduce_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums);
+  scan_reduce_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, overflow);
   GSR_CHECK_LAUNCH();
-  int rc = scan_impl(block_sums, block_sums, nb, nullptr, ws + used, stream);   // in place
+  int rc = scan_impl(block_sums, block_sums, nb, nullptr, ws + used, stream, overflow);   // in place
   if (rc != GSR_OK) return rc;
-  scan_apply_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, out, total_dev);
+  scan_apply_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, out, total_dev, overflow);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
@@ -339,6 +360,15 @@ int gsr_exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_
   if (n > 0 && (!in || !out)) return GSR_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < scan_ws_bytes((uint64_t)n) || (n > SCAN_TILE && !workspace)) return GSR_ERR_WORKSPACE_TOO_SMALL;
   return scan_impl(in, out, (uint64_t)n, total_dev, reinterpret_cast<uint8_t*>(workspace), stream);
+}
+
+int gsr_exclusive_scan_u32_checked(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* total_dev,
+                                   uint32_t* overflow_dev, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n < 0 || n > 0xFFFFFFFFll || !overflow_dev) return GSR_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (!in || !out)) return GSR_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < scan_ws_bytes((uint64_t)n) || (n > SCAN_TILE && !workspace)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  return scan_impl(in, out, (uint64_t)n, total_dev, reinterpret_cast<uint8_t*>(workspace), stream, overflow_dev);
 }
 
 size_t gsr_sort_workspace_bytes(int64_t n) { return sort_ws_bytes(n); }

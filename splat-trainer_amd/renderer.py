@@ -307,17 +307,17 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
   st.count = _u32(M, dev)
   st.offsets = _u32(M, dev)
-  total = torch.empty(1, dtype=torch.int32, device=dev)
+  total = torch.zeros(2, dtype=torch.int32, device=dev)          # [number of overlaps, overflow flag]
   _lib.check(lib.gsr_tile_count(_ptr(g2d), _ptr(depth), _ptr(feats), _ptr(st.order), M, C_, W, H,
                                 C.byref(st.params), _ptr(st.rec), _ptr(st.count), _ptr(st.screen_scale), stream),
              "gsr_tile_count")
   scan_bytes = lib.gsr_scan_workspace_bytes(M)
   scan_ws = torch.empty(scan_bytes, dtype=torch.uint8, device=dev)
-  _lib.check(lib.gsr_exclusive_scan_u32(_ptr(st.count), _ptr(st.offsets), M, _ptr(total), _ptr(scan_ws),
-                                        scan_bytes, stream), "gsr_exclusive_scan_u32")
-  O = int(total.item())          # host sync #2: number of (tile, splat) overlaps sizes the sort buffers
-  if O < 0:
-    raise _lib.GsplatHipError("tile overlap count overflowed 2^31")
+  _lib.check(lib.gsr_exclusive_scan_u32_checked(_ptr(st.count), _ptr(st.offsets), M, _ptr(total), _ptr(total[1:]),
+                                                _ptr(scan_ws), scan_bytes, stream), "gsr_exclusive_scan_u32_checked")
+  O, overflow = total.tolist()   # host sync #2: number of (tile, splat) overlaps sizes the sort buffers
+  if overflow or O < 0:          # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
+    raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
   st.O = O
   if O == 0:
     heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))

@@ -419,3 +419,18 @@ def test_sh_factor_exchange_equals_gradient_sum():
   assert rel_err(d_sh, 2 * pa[4].grad) < 2e-6
   for i in (1, 2, 3):                                          # the two SH forward variants (with / without the saved
     assert rel_err(pb[i].grad, pa[i].grad) < 1e-5              # Jacobian) may differ in the last bit of a colour
+
+
+def test_overlap_count_overflow_is_reported_not_wrapped():
+  """A few thousand screen-filling splats at 4K: sum of tile overlaps > 2^32.  The u32 scan would wrap to a small number
+  and the sort / composite buffers would be undersized; the guarded scan raises instead (renderer.py, host sync #2)."""
+  w, h = 3840, 2160
+  n = 200_000                                              # x 32 400 tiles = 6.5e9 overlaps
+  cam = sta.CameraParams(torch.eye(4), torch.tensor([2000., 2000., w / 2, h / 2]), (w, h)).to("cuda")
+  g2d = torch.zeros(n, 6, device="cuda")
+  g2d[:, 0], g2d[:, 1] = w / 2, h / 2
+  g2d[:, 2] = g2d[:, 4] = 1e-8                             # sigma = 1e4 px: the support covers every tile
+  g2d[:, 5] = 0.5
+  with pytest.raises(sta.GsplatHipError, match="2\\^31"):
+    sta.render_projected(torch.arange(n, device="cuda"), g2d, torch.rand(n, 3, device="cuda"),
+                         torch.rand(n, 1, device="cuda") + 1, cam, sta.RasterConfig())

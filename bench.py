@@ -6,9 +6,11 @@
         bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of synthetic input: every rank renders ITS camera of the
-batch (project -> SH colour -> tile bin/sort -> composite), takes the MSE loss against a constant image,
-back-propagates to the Gaussian parameters, and the parameter gradients (+ the per-point visibility
-accumulator) are summed over ranks with one fused RCCL collective.  Parameters are replicated; per-GPU
+batch (project -> SH colour -> tile bin/sort -> composite), takes the MSE loss of the clamped image against a constant
+image (fused pixel-loss kernels, loss.py), back-propagates to the Gaussian parameters, updates the controller's point
+statistics for the camera (PointState.add_rendering, the reference's per-camera consumer, trainer.py:514), and at N > 1
+the parameter gradients (+ the per-point visibility accumulator) and the per-camera statistics are exchanged over RCCL
+(distributed.CameraShardedStep) and the statistics of ALL cameras replayed in camera order on every rank.  Parameters are replicated; per-GPU
 work is fixed as N grows (weak scaling).  value = Gaussians x cameras / second over the whole job, inputs
 resident in HBM when the timed region starts.
 
@@ -231,7 +233,7 @@ def main():
   def render_backward(j, cam, grad_out, collector):
     with torch.enable_grad():
       r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
-      loss = torch.nn.functional.mse_loss(r.image.clamp(0, 1), target_image)    # trainer.py:472-475
+      loss = sta.clamped_mse_loss(r.image, target_image)      # = F.mse_loss(image.clamp(0, 1), target), trainer.py:472-475
       loss.backward()
     last["r"] = r
     return r

@@ -220,6 +220,16 @@ int gsr_ssim_backward(const float* img1, const float* img2, const int64_t* strid
                       const float* dm_dm11, const float* dm_dm12, const float* grad_scale_dev, float* d_img1,
                       void* stream);
 
+/* Pixel losses of the same stage (splat_trainer/trainer/trainer.py:465-488: l1 / mse on the image clamped to [0, 1]):
+ * loss_out[0] = mean(f(clamp(image, lo, hi) - target)), f = square (kind 0) or abs (kind 1), over n contiguous floats
+ * (16-byte aligned); fixed-order sums.  The backward writes grad_scale_dev[0] * d loss / d image, zero where the clamp
+ * is active (torch.clamp's rule). */
+size_t gsr_pixel_loss_workspace_bytes(int64_t n);
+int gsr_pixel_loss_forward(const float* image, const float* target, int64_t n, int32_t kind, float lo, float hi,
+                           float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+int gsr_pixel_loss_backward(const float* image, const float* target, int64_t n, int32_t kind, float lo, float hi,
+                            const float* grad_scale_dev, float* d_image, void* stream);
+
 /* ---- optimizer stage next to the path: sparse visibility-aware Adam / LaProp step on the
  *      rows a batch has seen; replaces the Taichi kernels behind taichi_splatting.optim.ParameterClass.step
  *      (splat_trainer/scene/mlp_scene.py:214-230, options :58-60, groups config/scene/mlp.yaml:8-14).  Arithmetic:

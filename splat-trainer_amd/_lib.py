@@ -76,6 +76,9 @@ PROTOTYPES = {
     "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _ps, _p]),
     "gsr_opt_point_weights": (C.c_int, [_p, _p, _i64, _p, _p, _f, _f, _f, _f, _i32, _p, _p]),
     "gsr_opt_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f, _f, _f, _f, _f, _p]),
+    "gsr_pixel_loss_workspace_bytes": (_sz, [_i64]),
+    "gsr_pixel_loss_forward": (C.c_int, [_p, _p, _i64, _i32, _f, _f, _p, _p, _sz, _p]),
+    "gsr_pixel_loss_backward": (C.c_int, [_p, _p, _i64, _i32, _f, _f, _p, _p, _p]),
     "gsr_ssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "gsr_ssim_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gsr_ssim_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),

@@ -209,6 +209,68 @@ Gauss11 make_gauss() {
   return g;
 }
 
+// ---- pixel losses of the same stage (splat_trainer/trainer/trainer.py:465-488: l1 / mse of the rendered image against
+// the target, the image clamped to [0, 1] by the scene's post-activation, scene/color_model.py:154-160).  As torch ops
+// that is clamp + sub + square + mean forward and four more elementwise passes backward over a 25 MB image; here one
+// pass computes mean(f(clamp(x, lo, hi) - t)), f = square or abs, with a fixed-order two-level sum, and one pass writes
+// the gradient (zero where the clamp is active, as torch.clamp's backward does).
+constexpr int PL_THREADS = 256;
+constexpr int PL_ITEMS = 8;      // floats per thread and round: two float4 loads
+
+template <int KIND>   // 0: squared error, 1: absolute error
+__global__ __launch_bounds__(PL_THREADS) void pixel_loss_fwd_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ t, int64_t n, float lo,
+                                                                    float hi, float* __restrict__ block_sums) {
+  __shared__ float s_w[PL_THREADS / 64];
+  float acc = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * PL_THREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * PL_THREADS * 4) {
+    float xv[4], tv[4];
+    if (i + 3 < n) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(t + i);
+      xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; tv[0] = b.x; tv[1] = b.y; tv[2] = b.z; tv[3] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { xv[k] = i + k < n ? x[i + k] : 0.f; tv[k] = i + k < n ? t[i + k] : fminf(fmaxf(0.f, lo), hi); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = fminf(fmaxf(xv[k], lo), hi) - tv[k];
+      acc += KIND == 0 ? d * d : fabsf(d);
+    }
+  }
+  acc = gsr_wave_sum(acc);
+  if (gsr_lane() == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(256) void pixel_loss_finish_kernel(const float* __restrict__ block_sums, int blocks,
+                                                                float inv_n, float* __restrict__ out) {
+  __shared__ float s_w[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < blocks; b += 256) acc += block_sums[b];
+  acc = gsr_wave_sum(acc);
+  if (gsr_lane() == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) * inv_n;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(PL_THREADS) void pixel_loss_bwd_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ t, int64_t n, float lo,
+                                                                    float hi, float inv_n,
+                                                                    const float* __restrict__ grad_scale,
+                                                                    float* __restrict__ dx) {
+  const float gs = grad_scale[0] * inv_n;
+  for (int64_t i = (int64_t)blockIdx.x * PL_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * PL_THREADS) {
+    const float xv = x[i];
+    const float d = fminf(fmaxf(xv, lo), hi) - t[i];
+    const bool pass = xv >= lo && xv <= hi;                       // torch.clamp backward: inclusive on both ends
+    const float g = KIND == 0 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    dx[i] = pass ? gs * g : 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -265,6 +327,41 @@ int gsr_ssim_backward(const float* img1, const float* img2, const int64_t* strid
   const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
   ssim_bwd_kernel<<<grid, 256, 0, stream>>>(img1, img2, s1, s2, so, C, H, W, make_gauss(), dm_dmu1, dm_dm11, dm_dm12,
                                            grad_scale_dev, d_img1);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+size_t gsr_pixel_loss_workspace_bytes(int64_t n) {
+  const int64_t blocks = (n + (int64_t)PL_THREADS * 4 - 1) / ((int64_t)PL_THREADS * 4);
+  return (size_t)(blocks < 1024 ? (blocks < 1 ? 1 : blocks) : 1024) * sizeof(float) + 256;
+}
+
+// loss_out[0] = mean(f(clamp(image, lo, hi) - target)), f = square (kind 0) or abs (kind 1); image / target contiguous.
+int gsr_pixel_loss_forward(const float* image, const float* target, int64_t n, int32_t kind, float lo, float hi,
+                           float* loss_out, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n <= 0 || !image || !target || !loss_out || (kind != 0 && kind != 1) || !(lo <= hi)) return GSR_ERR_INVALID_ARGUMENT;
+  if (!workspace || workspace_bytes < gsr_pixel_loss_workspace_bytes(n)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  if ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(target)) & 15) return GSR_ERR_INVALID_ARGUMENT;
+  const int64_t want = (n + (int64_t)PL_THREADS * 4 - 1) / ((int64_t)PL_THREADS * 4);
+  const int blocks = (int)(want < 1024 ? want : 1024);
+  float* sums = reinterpret_cast<float*>(workspace);
+  if (kind == 0) pixel_loss_fwd_kernel<0><<<blocks, PL_THREADS, 0, stream>>>(image, target, n, lo, hi, sums);
+  else pixel_loss_fwd_kernel<1><<<blocks, PL_THREADS, 0, stream>>>(image, target, n, lo, hi, sums);
+  pixel_loss_finish_kernel<<<1, 256, 0, stream>>>(sums, blocks, 1.f / (float)n, loss_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+// d_image = grad_scale_dev[0] * d loss / d image (zero where the clamp is active).
+int gsr_pixel_loss_backward(const float* image, const float* target, int64_t n, int32_t kind, float lo, float hi,
+                            const float* grad_scale_dev, float* d_image, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (n <= 0 || !image || !target || !grad_scale_dev || !d_image || (kind != 0 && kind != 1)) return GSR_ERR_INVALID_ARGUMENT;
+  const int64_t want = (n + PL_THREADS - 1) / PL_THREADS;
+  const int blocks = (int)(want < 8192 ? want : 8192);
+  if (kind == 0) pixel_loss_bwd_kernel<0><<<blocks, PL_THREADS, 0, stream>>>(image, target, n, lo, hi, 1.f / (float)n, grad_scale_dev, d_image);
+  else pixel_loss_bwd_kernel<1><<<blocks, PL_THREADS, 0, stream>>>(image, target, n, lo, hi, 1.f / (float)n, grad_scale_dev, d_image);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

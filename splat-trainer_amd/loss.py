@@ -76,3 +76,49 @@ def fused_ssim(img1: torch.Tensor, img2: torch.Tensor, padding: str = "same", tr
     raise ValueError("image too small for padding='valid' (needs more than 10 pixels per side)")
   train = bool(train and torch.is_grad_enabled() and img1.requires_grad)
   return _SSIMFn.apply(img1, img2, crop, train)
+
+
+class _PixelLossFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, image, target, kind, lo, hi):
+    lib = _lib.load()
+    x = image.detach().to(torch.float32).contiguous()
+    t = target.detach().to(torch.float32).expand_as(x).contiguous()
+    n = x.numel()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.gsr_pixel_loss_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.gsr_pixel_loss_forward(_ptr(x), _ptr(t), n, kind, lo, hi, _ptr(out), _ptr(ws), ws_bytes, _stream()),
+               "gsr_pixel_loss_forward")
+    ctx.save_for_backward(x, t)
+    ctx.args = (kind, lo, hi, image.dtype)
+    return out[0]
+
+  @staticmethod
+  def backward(ctx, g):
+    lib = _lib.load()
+    x, t = ctx.saved_tensors
+    kind, lo, hi, dtype = ctx.args
+    gs = g.detach().to(torch.float32).reshape(1).contiguous()
+    d = torch.empty_like(x)
+    _lib.check(lib.gsr_pixel_loss_backward(_ptr(x), _ptr(t), x.numel(), kind, lo, hi, _ptr(gs), _ptr(d), _stream()),
+               "gsr_pixel_loss_backward")
+    return d.to(dtype), None, None, None, None
+
+
+def _pixel_loss(image, target, kind, clamp):
+  if not (image.is_cuda and target.is_cuda):
+    raise _lib.GsplatHipError("the fused pixel losses run only on a HIP device; there is no CPU fallback")
+  lo, hi = (float(clamp[0]), float(clamp[1])) if clamp is not None else (-3.0e38, 3.0e38)
+  return _PixelLossFn.apply(image, target, kind, lo, hi)
+
+
+def clamped_mse_loss(image: torch.Tensor, target: torch.Tensor, clamp=(0.0, 1.0)) -> torch.Tensor:
+  """``F.mse_loss(image.clamp(*clamp), target)`` (trainer.py:472-475 on the post-activation image,
+  scene/color_model.py:154-160) in one forward pass + one backward pass; ``clamp=None``: no clamp."""
+  return _pixel_loss(image, target, 0, clamp)
+
+
+def clamped_l1_loss(image: torch.Tensor, target: torch.Tensor, clamp=(0.0, 1.0)) -> torch.Tensor:
+  """``F.l1_loss(image.clamp(*clamp), target)`` (trainer.py:470-471), fused the same way."""
+  return _pixel_loss(image, target, 1, clamp)

@@ -116,3 +116,27 @@ def test_reference_multiscale_loss_flow():
   assert abs(loss.item() - oloss.item()) < 2e-6 and abs(s0 - os0.item()) < 2e-6
   err = (pd.grad.cpu().double() - po.grad).abs().max().item() / po.grad.abs().max().item()
   assert err < 1e-4, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(37, 53, 3), (1080, 1920, 3), (5,)])
+def test_fused_pixel_losses_match_torch(shape):
+  """clamped_mse_loss / clamped_l1_loss (csrc/ssim.hip: pixel_loss_*) vs F.mse_loss / F.l1_loss on the clamped image,
+  value and gradient, incl. pixels outside [0, 1] (zero gradient) and exactly on the clamp bounds (gradient passes)."""
+  import torch.nn.functional as F
+  import splat_trainer_amd as sta
+  gen = torch.Generator(device="cuda").manual_seed(1)
+  x0 = torch.rand(shape, device="cuda", generator=gen) * 1.6 - 0.3
+  x0.view(-1)[0], x0.view(-1)[1] = 0.0, 1.0
+  t = torch.rand(shape, device="cuda", generator=gen)
+  for fused, ref in ((sta.clamped_mse_loss, F.mse_loss), (sta.clamped_l1_loss, F.l1_loss)):
+    a = x0.clone().requires_grad_(True)
+    b = x0.clone().requires_grad_(True)
+    la = fused(a, t) * 3.0
+    lb = ref(b.clamp(0, 1), t) * 3.0
+    la.backward()
+    lb.backward()
+    assert torch.allclose(la, lb, rtol=2e-6, atol=1e-8), (la.item(), lb.item())
+    assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-12)
+  c = x0.clone().requires_grad_(True)
+  assert torch.allclose(sta.clamped_mse_loss(c, t, clamp=None), F.mse_loss(x0, t), rtol=2e-6)

@@ -54,20 +54,17 @@ def test_random_scene_matches_oracle(seed):
   hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
   orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
   assert len(set(hip["idx"].tolist()) ^ set(orc["idx"].tolist())) == 0
-  # Extreme anisotropy makes the conic ill-conditioned: fp32 vs fp64 inputs move the q = 9 support boundary by a
-  # relative 1e-4..1e-3, so a small fraction of boundary pixels legitimately flips.  This sweep is a net for gross
-  # errors (missed tiles, wrong half masks, wrong order); the 1e-4 criterion is enforced on the well-conditioned
-  # scenes of test_gpu_render.py.
-  tol = 1e-3
+  # Extreme anisotropy makes the conic ill-conditioned, so this sweep (a net for gross errors: missed tiles, wrong half
+  # masks, wrong order) runs at 2e-4 instead of 1e-4 -- with NO outliers allowed.  Observed over the 32 seeds
+  # (profiles/r02_parity_observed.txt): largest error 7.7e-5, nothing above 1e-4.
+  tol = 2e-4
   for k in ("image", "final_T"):
     worst, frac = observe(f"fuzz seed {seed}", k, hip[k], orc[k], tol)
-    assert frac <= 1e-2, (seed, k, frac)
-    assert worst < 0.03, (seed, k, worst)
+    assert frac == 0 and worst < tol, (seed, k, frac, worst)
   for k in ("visibility", "prune_cost", "split_score", "screen_scale", "depth", "d_position", "d_log_scaling",
             "d_rotation", "d_alpha_logit", "d_feature"):
     if orc[k].abs().max() == 0:
       assert hip[k].abs().max() == 0, (seed, k)
       continue
     worst, frac = observe(f"fuzz seed {seed}", k, hip[k], orc[k], tol)
-    assert frac <= 1e-2, (seed, k, frac, worst)
-    assert worst < 3e-2, (seed, k, worst)
+    assert frac == 0 and worst < tol, (seed, k, frac, worst)

@@ -328,8 +328,8 @@ def test_culled_orbit_scene_matches_oracle():
   assert orc["screen_scale"].max() > 30                       # at least one very large splat
   # splats hundreds of pixels wide right in front of the camera: one pixel of 64 000 sits within fp32 rounding of a
   # contribute/skip boundary and flips against the fp64 oracle (observed: 3 image entries, largest 4.9e-3)
-  compare_to_oracle("culled orbit, huge near-camera splats", hip, orc, TOL, pixel_flips=5e-5, point_flips=1e-3,
-                    worst_pixel=1e-2, worst_point=5e-3)
+  compare_to_oracle("culled orbit, huge near-camera splats", hip, orc, TOL, pixel_flips=3e-5, point_flips=5e-4,
+                    worst_pixel=1e-2, worst_point=5e-4)       # observed: 1 pixel (4.9e-3), 1 split_score entry (1.2e-4)
 
 
 def test_two_channel_features_and_no_visibility():

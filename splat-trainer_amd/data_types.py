@@ -34,7 +34,8 @@ class RasterConfig:
   compute_visibility: bool = False    # fill points.visibility (sum_pixels T*alpha) in forward
   compute_point_heuristic: bool = False  # fill prune_cost / split_score in backward
   segment_pairs: int = 256            # heavy tiles: list segments of at most this many (tile, splat) pairs; 0 = off
-  segment_min_pairs: int = 512        # a tile is heavy (its list is segmented) above this many pairs
+  segment_min_pairs: int = 0          # a tile is heavy (its list is segmented) above this many pairs; 0 = chosen per
+                                      # frame from the overlap count (renderer._segment_thresholds)
 
   @property
   def transmittance_eps(self) -> float:

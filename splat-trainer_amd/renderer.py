@@ -243,6 +243,18 @@ def _launch_depth_order(depth: torch.Tensor, M: int) -> torch.Tensor:
   return vals_b if where == 1 else vals_a
 
 
+def _segment_thresholds(seg_pairs: int, seg_min: int, O: int):
+  """(segment length, heavy-tile threshold) of a frame.  Cutting a tile's list only pays when that tile would otherwise
+  outlast the rest of the launch: the forward pass of a segmented tile costs an extra alpha-product pass, so a frame
+  whose tiles are all equally long (3M splats at 1080p: ~800 pairs on EVERY tile) must not be segmented at all.  A
+  lone wave walks ~6 pairs per microsecond while the balanced launch takes ~(40 + 0.11 O / 1000) us (measured K6 fit),
+  so a tile is heavy above about half of what one wave can walk in that time; segments are half a threshold long."""
+  if seg_min > 0:
+    return seg_pairs, max(seg_min, seg_pairs)
+  heavy = max(2 * seg_pairs, 120 + O // 2900)
+  return max(seg_pairs, heavy // 2), heavy
+
+
 def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream, seg_total: torch.Tensor):
   """Heavy-tile list segmentation (composite.hip): tiles with more than ``segment_min_pairs`` pairs are cut into
   segments of at most ``segment_pairs``; returns the GsrSegmentsC the composite calls take, or None when switched off.
@@ -252,12 +264,13 @@ def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream, seg_
   if st.seg_pairs <= 0:
     return None
   lib = _lib.load()
-  cap = int(lib.gsr_segment_capacity(O, st.seg_pairs, st.seg_min))
+  seg_pairs, seg_min = _segment_thresholds(st.seg_pairs, st.seg_min, O)
+  cap = int(lib.gsr_segment_capacity(O, seg_pairs, seg_min))
   if cap <= 0:
     return None
   tables = torch.empty(2 * num_tiles + 4 * cap, dtype=torch.int32, device=dev)
   tile_seg, seg_desc = tables[:2 * num_tiles], tables[2 * num_tiles:]
-  _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, st.seg_pairs, st.seg_min, cap, _ptr(tile_seg),
+  _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, seg_pairs, seg_min, cap, _ptr(tile_seg),
                                   _ptr(seg_desc), _ptr(seg_total), stream), "gsr_segment_plan")
   planes = 2 + st.C + (1 if st.want_median else 0)
   pix = torch.empty(planes * cap * 256, dtype=torch.float32, device=dev)
@@ -435,7 +448,7 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
   st.pair_vis = None
   st.segments = None
   st.segment_buffers = None
-  st.seg_pairs, st.seg_min = int(config.segment_pairs), int(max(config.segment_min_pairs, config.segment_pairs))
+  st.seg_pairs, st.seg_min = int(config.segment_pairs), int(config.segment_min_pairs)
   st.needs_grad = torch.is_grad_enabled() and (gaussians2d.requires_grad or features.requires_grad)
   order = None
   if _depth_order is not None and _depth_order[1] is depth and _depth_order[2] == depth._version:

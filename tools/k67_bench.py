@@ -24,7 +24,8 @@ else:
   g, cams = synthetic.scene_b(3_000_000, 1920, 1080, sh_degree=3, seed=1, num_cameras=8)
   cam = cams[0]
 g, cam = g.to("cuda"), cam.to("cuda")
-cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True,
+                       segment_pairs=int(os.environ.get("SEG_PAIRS", "256")), segment_min_pairs=int(os.environ.get("SEG_MIN", "0")))
 params = [t.requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
 scene = sta.Gaussians3D(position=params[0], log_scaling=params[1], rotation=params[2], alpha_logit=params[3], feature=params[4])
 
@@ -54,6 +55,6 @@ ks = timer.summary()
 h = hashlib.sha256()
 for t in (r.image, r.points.prune_cost, r.points.split_score, r.points.visibility) + tuple(p.grad for p in params):
   h.update(t.detach().cpu().numpy().tobytes())
-print(f"{os.environ.get('GSPLAT_HIP_LIB', 'product')}: {which} O {r.num_overlaps}  K6 {ks['composite_forward'][1] * 1e3:.1f} us  "
+print(f"{os.environ.get('GSPLAT_HIP_LIB', 'product')} seg {cfg.segment_pairs}/{cfg.segment_min_pairs}: {which} O {r.num_overlaps}  K6 {ks['composite_forward'][1] * 1e3:.1f} us  "
       f"K7 {ks['composite_backward'][1] * 1e3:.1f} us  step {e0.elapsed_time(e1) / steps * 1e3:.0f} us  digest {h.hexdigest()[:16]}",
       flush=True)

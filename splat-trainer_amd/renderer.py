@@ -163,6 +163,7 @@ class _ProjectFn(torch.autograd.Function):
       # works its way to render_projected (the GPU would otherwise idle behind the sync)
       prefetch["order"] = _launch_depth_order(depth.reshape(-1), M)
     ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
+    ctx.set_materialize_grads(False)       # an unused output (depth, usually) arrives as None, not as a zero-filled tensor
     ctx.params = params
     ctx.grad_out = grad_out
     ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype)
@@ -179,9 +180,10 @@ class _ProjectFn(torch.autograd.Function):
       d_pos, d_ls = go._check("position", pos), go._check("log_scaling", ls)
       d_rot, d_al = go._check("rotation", rot), go._check("alpha_logit", al)
     else:
-      alloc = torch.empty_like if M == N else torch.zeros_like      # every row is written when nothing was culled
+      live = M > 0 and (d_g2d is not None or d_depth is not None)
+      alloc = torch.empty_like if (M == N and live) else torch.zeros_like   # every row is written when nothing was culled
       d_pos, d_ls, d_rot, d_al = alloc(pos), alloc(ls), alloc(rot), alloc(al)
-    if M > 0:
+    if M > 0 and (d_g2d is not None or d_depth is not None):
       dg = _f32c(d_g2d) if d_g2d is not None else torch.zeros(M, 6, dtype=torch.float32, device=pos.device)
       dd = _f32c(d_depth) if d_depth is not None else None
       _lib.check(lib.gsr_project_backward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M, _ptr(T),

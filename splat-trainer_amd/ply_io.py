@@ -22,74 +22,68 @@ import torch.nn.functional as F
 from .data_types import Gaussians3D
 
 
-def _field_names(feature: torch.Tensor, with_sh: bool) -> List[str]:
-  names = ["x", "y", "z", "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+_GEOMETRY_COLUMNS = ("x", "y", "z", "opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3")
+
+
+def _feature_columns(feature: torch.Tensor, with_sh: bool) -> List[str]:
+  """Column names of the colour block: f_dc_* then channel-major f_rest_* for SH, f_* for plain features."""
   if with_sh:
-    assert feature.ndim == 3, f"Expected ndim=3 sh_feature tensor, got {tuple(feature.shape)}"
-    num_sh = feature.shape[2] * feature.shape[1]
-    names += ["f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(num_sh - 3)]
-  else:
-    assert feature.ndim == 2, f"Expected ndim=2 feature tensor, got {tuple(feature.shape)}"
-    names += [f"f_{i}" for i in range(feature.shape[1])]
-  return names
+    if feature.ndim != 3 or feature.shape[1] != 3:
+      raise ValueError(f"with_sh=True needs (N, 3, K) SH coefficients, got {tuple(feature.shape)}")
+    return [f"f_dc_{c}" for c in range(3)] + [f"f_rest_{i}" for i in range(3 * (feature.shape[2] - 1))]
+  if feature.ndim != 2:
+    raise ValueError(f"with_sh=False needs (N, F) features, got {tuple(feature.shape)}")
+  return [f"f_{i}" for i in range(feature.shape[1])]
 
 
 def to_vertex_array(gaussians: Gaussians3D, with_sh: bool = False) -> np.ndarray:
-  """Structured float32 array with the reference's field names and order (io.py:13-67)."""
-  g = gaussians
-  pos, ls = g.position.detach().cpu(), g.log_scaling.detach().cpu()
-  feat, al = g.feature.detach().cpu(), g.alpha_logit.detach().cpu()
-  names = _field_names(feat, with_sh)
-  vertex = np.zeros(pos.shape[0], dtype=[(n, "<f4") for n in names])
-  for i, n in enumerate(["x", "y", "z"]):
-    vertex[n] = pos[:, i].numpy()
-  for i in range(3):
-    vertex[f"scale_{i}"] = ls[:, i].numpy()
-  rotation = torch.roll(F.normalize(g.rotation.detach().cpu(), dim=1), 1, dims=(1,))      # xyzw -> wxyz
-  for i in range(4):
-    vertex[f"rot_{i}"] = rotation[:, i].numpy()
-  vertex["opacity"] = al[:, 0].numpy()
+  """Gaussians -> structured float32 vertex array in the 3DGS column order (what io.py:13-67 produces through plyfile).
+  The table is assembled as one dense (N, columns) float32 matrix -- geometry block, then the colour block with the
+  DC coefficients first and the higher bands channel-major -- and reinterpreted as the record array."""
+  cpu = lambda t: t.detach().to("cpu", torch.float32)
+  feature = cpu(gaussians.feature)
+  quat_wxyz = F.normalize(cpu(gaussians.rotation), dim=1)[:, [3, 0, 1, 2]]                 # memory xyzw -> disk wxyz
   if with_sh:
-    sh_dc, sh_rest = feat[:, :, 0], feat[:, :, 1:]
-    sh_rest = sh_rest.reshape(sh_rest.shape[0], sh_rest.shape[1] * sh_rest.shape[2])
-    for i in range(3):
-      vertex[f"f_dc_{i}"] = sh_dc[:, i].numpy()
-    for i in range(sh_rest.shape[1]):
-      vertex[f"f_rest_{i}"] = sh_rest[:, i].numpy()
+    colour = torch.cat([feature[:, :, 0], feature[:, :, 1:].flatten(1)], dim=1)
   else:
-    for i in range(feat.shape[1]):
-      vertex[f"f_{i}"] = feat[:, i].numpy()
-  return vertex
+    colour = feature
+  columns = list(_GEOMETRY_COLUMNS) + _feature_columns(feature, with_sh)
+  table = torch.cat([cpu(gaussians.position), cpu(gaussians.alpha_logit).reshape(-1, 1), cpu(gaussians.log_scaling),
+                     quat_wxyz, colour], dim=1).contiguous()
+  assert table.shape[1] == len(columns)
+  records = np.dtype([(name, "<f4") for name in columns])
+  return table.numpy().view(records).reshape(-1)
 
 
 def from_vertex_array(vertex: np.ndarray, with_sh: bool = False) -> Gaussians3D:
-  """io.py:70-117."""
-  def get_keys(ks):
-    return torch.stack([torch.from_numpy(np.ascontiguousarray(vertex[k]).astype(np.float32)) for k in ks], dim=-1)
+  """Structured vertex array (any column order, any float width) -> Gaussians; inverse of to_vertex_array
+  (io.py:70-117): quaternion back to xyzw, SH rebuilt as (N, 3, K) from f_dc_* and channel-major f_rest_*."""
+  present = set(vertex.dtype.names)
+
+  def block(names) -> torch.Tensor:
+    missing = [k for k in names if k not in present]
+    if missing:
+      raise KeyError(f"PLY vertex element lacks {missing}")
+    return torch.from_numpy(np.stack([np.asarray(vertex[k], dtype=np.float32) for k in names], axis=1))
 
   n = vertex.shape[0]
-  positions = get_keys(["x", "y", "z"])
-  attrs = sorted(vertex.dtype.names)
-  log_scaling = get_keys([f"scale_{k}" for k in range(3)])
   if with_sh:
-    sh_attrs = [k for k in attrs if k.startswith("f_rest_") or k.startswith("f_dc_")]
-    n_sh = len(sh_attrs) // 3
-    deg = int(np.sqrt(n_sh))
-    assert deg * deg == n_sh, f"SH feature count must be square ({deg} * {deg} != {n_sh}), got {len(sh_attrs)}"
-    sh_dc = get_keys([f"f_dc_{k}" for k in range(3)]).view(n, 3, 1)
-    if n_sh > 1:
-      sh_rest = get_keys([f"f_rest_{k}" for k in range(3 * (n_sh - 1))]).view(n, 3, n_sh - 1)
-      features = torch.cat([sh_dc, sh_rest], dim=2)
-    else:
-      features = sh_dc
+    coeffs = sum(1 for k in present if k.startswith("f_dc_") or k.startswith("f_rest_"))
+    per_channel = coeffs // 3
+    degree_plus_1 = int(round(per_channel ** 0.5))
+    if coeffs != 3 * per_channel or degree_plus_1 ** 2 != per_channel:
+      raise ValueError(f"{coeffs} SH columns are not 3 x (degree + 1)^2")
+    feature = block([f"f_dc_{c}" for c in range(3)]).reshape(n, 3, 1)
+    if per_channel > 1:
+      rest = block([f"f_rest_{i}" for i in range(3 * (per_channel - 1))]).reshape(n, 3, per_channel - 1)
+      feature = torch.cat([feature, rest], dim=2)
   else:
-    feature_attrs = [k for k in attrs if k.startswith("f_")]
-    features = get_keys([f"f_{k}" for k in range(len(feature_attrs))])
-  rotation = get_keys([f"rot_{k}" for k in range(4)])
-  rotation = torch.roll(F.normalize(rotation, dim=1), -1, dims=(1,))                       # wxyz -> xyzw
-  alpha_logit = get_keys(["opacity"])
-  return Gaussians3D(position=positions, rotation=rotation, log_scaling=log_scaling, alpha_logit=alpha_logit,
-                     feature=features)
+    width = sum(1 for k in present if k.startswith("f_") and k[2:].isdigit())
+    feature = block([f"f_{i}" for i in range(width)])
+  quat_xyzw = F.normalize(block([f"rot_{i}" for i in range(4)]), dim=1)[:, [1, 2, 3, 0]]   # disk wxyz -> memory xyzw
+  return Gaussians3D(position=block(["x", "y", "z"]), rotation=quat_xyzw,
+                     log_scaling=block([f"scale_{i}" for i in range(3)]), alpha_logit=block(["opacity"]),
+                     feature=feature, batch_size=(n,))
 
 
 _PLY_TYPES = {"float": "<f4", "float32": "<f4", "double": "<f8", "float64": "<f8", "uchar": "u1", "uint8": "u1",

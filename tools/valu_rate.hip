@@ -74,6 +74,24 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
       asm volatile(REP8("v_rcp_f32 %0, %0", "v_rcp_f32 %1, %1", "v_rcp_f32 %2, %2", "v_rcp_f32 %3, %3", "v_rcp_f32 %4, %4", "v_rcp_f32 %5, %5",
                         "v_rcp_f32 %6, %6", "v_rcp_f32 %7, %7")
                    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (MODE == 14) {  // v_fma_f32 with only lanes 0-31 enabled: does the SIMD skip the inactive half-wave?
+      asm volatile("s_mov_b64 s[20:21], exec\ns_mov_b64 exec, 0xffffffff\n"
+                   "v_fma_f32 %0, %0, %8, %9\nv_fma_f32 %1, %1, %8, %9\nv_fma_f32 %2, %2, %8, %9\nv_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\nv_fma_f32 %5, %5, %8, %9\nv_fma_f32 %6, %6, %8, %9\nv_fma_f32 %7, %7, %8, %9\n"
+                   "s_mov_b64 exec, s[20:21]\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "s20", "s21");
+    } else if (MODE == 15) {  // v_pk_fma_f32 with only lanes 0-31 enabled
+      asm volatile("s_mov_b64 s[20:21], exec\ns_mov_b64 exec, 0xffffffff\n"
+                   "v_pk_fma_f32 %0, %0, %8, %9\nv_pk_fma_f32 %1, %1, %8, %9\nv_pk_fma_f32 %2, %2, %8, %9\nv_pk_fma_f32 %3, %3, %8, %9\n"
+                   "v_pk_fma_f32 %4, %4, %8, %9\nv_pk_fma_f32 %5, %5, %8, %9\nv_pk_fma_f32 %6, %6, %8, %9\nv_pk_fma_f32 %7, %7, %8, %9\n"
+                   "s_mov_b64 exec, s[20:21]\n"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(va), "v"(vb) : "s20", "s21");
+    } else if (MODE == 16) {  // v_fma_f32 with lanes 0-15 only
+      asm volatile("s_mov_b64 s[20:21], exec\ns_mov_b64 exec, 0xffff\n"
+                   "v_fma_f32 %0, %0, %8, %9\nv_fma_f32 %1, %1, %8, %9\nv_fma_f32 %2, %2, %8, %9\nv_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\nv_fma_f32 %5, %5, %8, %9\nv_fma_f32 %6, %6, %8, %9\nv_fma_f32 %7, %7, %8, %9\n"
+                   "s_mov_b64 exec, s[20:21]\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "s20", "s21");
     } else if (MODE == 13) {  // mix of 4 v_pk_fma (sgpr src) + 4 v_fma: does alternating help?
       asm volatile(REP8("v_pk_fma_f32 %0, %8, %9, %0", "v_fma_f32 %4, %4, %10, %10", "v_pk_fma_f32 %1, %8, %9, %1", "v_fma_f32 %5, %5, %10, %10",
                         "v_pk_fma_f32 %2, %8, %9, %2", "v_fma_f32 %6, %6, %10, %10", "v_pk_fma_f32 %3, %8, %9, %3", "v_fma_f32 %7, %7, %10, %10")
@@ -120,9 +138,14 @@ template <int MODE> void run(const char* name, float* out, unsigned long long* c
            name, wps, ns_per_instr, ns_per_instr * 2.4, ramp_us, avg, clock_ghz);
   }
 }
-int main() {
+int main(int argc, char** argv) {
   float* out; hipMalloc(&out, 256 * 4 * 8 * 64 * 4);
   unsigned long long* cyc; hipMalloc(&cyc, 256 * 4 * 8 * 8);
+  if (argc > 1) {   // quick check: half-wave EXEC masks
+    run<0>("v_fma_f32 vvv", out, cyc); run<14>("v_fma_f32 exec lo32", out, cyc); run<16>("v_fma_f32 exec lo16", out, cyc);
+    run<1>("v_pk_fma_f32 vvv", out, cyc); run<15>("v_pk_fma_f32 exec lo32", out, cyc);
+    return 0;
+  }
   run<0>("v_fma_f32 vvv", out, cyc); run<2>("v_mul_f32 vop2", out, cyc); run<1>("v_pk_fma_f32 vvv", out, cyc);
   run<5>("v_pk_fma_f32 v,s,acc", out, cyc); run<3>("v_pk_mul_f32 vv", out, cyc); run<4>("v_pk_mul_f32 v,s", out, cyc);
   run<6>("v_pk_add_f32 vv", out, cyc); run<7>("v_exp_f32", out, cyc); run<12>("v_rcp_f32", out, cyc);

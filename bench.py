@@ -210,7 +210,7 @@ def main():
   import splat_trainer_amd as sta
   from splat_trainer_amd import renderer
   from splat_trainer_amd.controller_math import PointState
-  from splat_trainer_amd.distributed import CameraShardedStep, GradBucket, replay_point_stats
+  from splat_trainer_amd.distributed import CameraShardedStep
 
   g, cams, w = make_workload(args.workload, world)
   cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True, blur_cov=0.3, antialias=False)
@@ -239,8 +239,8 @@ def main():
     return r
 
   def step():
-    stats = dp.run(batch, render_backward)
-    replay_point_stats(point_state, stats)        # controller.add_rendering for every camera of the batch, in order
+    # controller.add_rendering for every camera of the batch (trainer.py:514), in camera order on every rank
+    dp.run(batch, render_backward, point_state=point_state)
 
   def sync():
     torch.cuda.synchronize()

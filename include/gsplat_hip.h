@@ -276,7 +276,9 @@ int gsr_compact_columns(const uint8_t* keep_mask, int64_t N, const uint32_t* blo
  * the camera's list, with i = idx[m]:  max_scale_px[i] = max(., max over the scale_cols (1 or 2) columns of
  * screen_scale[m]);  points_in_view[i] += visibility[m] > 0;  visibility[i] += visibility[m];
  * split_score[i] = exp_lerp(split_alpha, ., split_score[m]);  prune_cost[i] = exp_lerp(prune_alpha, ., prune_cost[m]).
- * idx rows are unique (one camera); the state arrays have N entries (points_in_view int16). */
+ * idx rows are unique (one camera; NULL = rows are the points 0..M-1); the state arrays have N entries (points_in_view
+ * int16).  Each input group is optional: a NULL screen_scale / visibility / split_score / prune_cost leaves the
+ * corresponding state untouched (the data-parallel exchange replays only the two EMAs per camera and reduces the rest). */
 int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t scale_cols, const float* visibility,
                         const float* split_score, const float* prune_cost, int64_t M, float split_alpha,
                         float prune_alpha, float* state_prune_cost, float* state_split_score, float* state_max_scale_px,

@@ -51,6 +51,19 @@ class PointState:
     self.split_score[points.idx] = exp_lerp(split_alpha, self.split_score[points.idx], points.split_score)
     self.prune_cost[points.idx] = exp_lerp(prune_alpha, self.prune_cost[points.idx], points.prune_cost)
 
+  def add_scores(self, idx, split_score: torch.Tensor, prune_cost: torch.Tensor, split_alpha: float = 0.01,
+                 prune_alpha: float = 0.1):
+    """The order-dependent part of add_rendering alone: the two exp_lerp EMAs over the rows ``idx`` (None: all points).
+    Used by the data-parallel exchange, which replays only these per camera and reduces the rest."""
+    if self.prune_cost.is_cuda:
+      from .densify import point_state_update
+      point_state_update(self, idx, split_score=split_score, prune_cost=prune_cost, split_alpha=split_alpha,
+                         prune_alpha=prune_alpha)
+      return
+    rows = slice(None) if idx is None else idx
+    self.split_score[rows] = exp_lerp(split_alpha, self.split_score[rows], split_score)
+    self.prune_cost[rows] = exp_lerp(prune_alpha, self.prune_cost[rows], prune_cost)
+
   def masked_heuristics(self, min_views: int):
     seen = self.points_in_view >= min_views
     prune_cost = torch.where(seen, self.prune_cost, torch.full_like(self.prune_cost, torch.inf))

@@ -211,15 +211,19 @@ __global__ __launch_bounds__(DN_THREADS) void point_state_add_kernel(const int64
                                                                      float* __restrict__ st_vis) {
   const int64_t m = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
   if (m >= M) return;
-  const int64_t i = idx[m];                       // rows of one camera are unique: no two threads share a point
-  float sc = scale[m * scale_cols];
-  if (scale_cols == 2) sc = fmaxf(sc, scale[m * 2 + 1]);
-  const float v = vis[m];
-  st_scale[i] = fmaxf(st_scale[i], sc);
-  if (v > 0.f) st_views[i] = (int16_t)(st_views[i] + 1);
-  st_vis[i] += v;
-  st_split[i] = exp_lerp(split_alpha, st_split[i], split[m]);
-  st_prune[i] = exp_lerp(prune_alpha, st_prune[i], prune[m]);
+  const int64_t i = idx ? idx[m] : m;             // rows of one camera are unique: no two threads share a point
+  if (scale) {                                    // every group of updates is optional (NULL input = leave that state alone)
+    float sc = scale[m * scale_cols];
+    if (scale_cols == 2) sc = fmaxf(sc, scale[m * 2 + 1]);
+    st_scale[i] = fmaxf(st_scale[i], sc);
+  }
+  if (vis) {
+    const float v = vis[m];
+    if (v > 0.f) st_views[i] = (int16_t)(st_views[i] + 1);
+    st_vis[i] += v;
+  }
+  if (split) st_split[i] = exp_lerp(split_alpha, st_split[i], split[m]);
+  if (prune) st_prune[i] = exp_lerp(prune_alpha, st_prune[i], prune[m]);
 }
 
 }  // namespace
@@ -233,8 +237,8 @@ int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t s
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || (scale_cols != 1 && scale_cols != 2)) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
-  if (!idx || !screen_scale || !visibility || !split_score || !prune_cost || !state_prune_cost || !state_split_score ||
-      !state_max_scale_px || !state_points_in_view || !state_visibility)
+  if ((screen_scale && !state_max_scale_px) || (visibility && (!state_points_in_view || !state_visibility)) ||
+      (split_score && !state_split_score) || (prune_cost && !state_prune_cost))
     return GSR_ERR_INVALID_ARGUMENT;
   point_state_add_kernel<<<dn_grid(M, DN_THREADS), DN_THREADS, 0, stream>>>(
       idx, screen_scale, scale_cols, visibility, split_score, prune_cost, M, split_alpha, prune_alpha, state_prune_cost,

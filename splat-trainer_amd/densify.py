@@ -103,21 +103,34 @@ def point_state_add(state, points, split_alpha: float = 0.01, prune_alpha: float
   """``PointState.add_rendering`` (splat_trainer/controller/point_state.py:34-50) for one camera in one launch, in place
   on the state's device tensors.  ``points``: RenderedPoints (idx, screen_scale (M,2) or (M,), visibility, split_score,
   prune_cost)."""
+  return point_state_update(state, points.idx, screen_scale=points.screen_scale, visibility=points.visibility,
+                            split_score=points.split_score, prune_cost=points.prune_cost, split_alpha=split_alpha,
+                            prune_alpha=prune_alpha)
+
+
+def point_state_update(state, idx, screen_scale=None, visibility=None, split_score=None, prune_cost=None,
+                       split_alpha: float = 0.01, prune_alpha: float = 0.1):
+  """The fused update with every input group optional (``None`` leaves that part of the state alone); ``idx = None``:
+  the rows are the points 0..M-1.  The data-parallel exchange uses it to replay only the two order-dependent EMAs per
+  camera (distributed.exchange_point_stats)."""
   lib = _lib.load()
-  idx = points.idx.contiguous()
-  M = idx.shape[0]
+  given = [t for t in (screen_scale, visibility, split_score, prune_cost) if t is not None]
+  if not given:
+    return state
+  M = int(idx.shape[0]) if idx is not None else int(given[0].shape[0])
   if M == 0:
     return state
-  f32 = lambda t: t.detach().to(torch.float32).contiguous()
-  scale = f32(points.screen_scale)
-  cols = 2 if scale.dim() == 2 else 1
+  f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+  scale = f32(screen_scale)
+  cols = 2 if (scale is not None and scale.dim() == 2) else 1
   for t in (state.prune_cost, state.split_score, state.max_scale_px, state.visibility):
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-      raise _lib.GsplatHipError("point_state_add needs contiguous float32 CUDA state tensors (no CPU fallback)")
+      raise _lib.GsplatHipError("point_state_update needs contiguous float32 CUDA state tensors (no CPU fallback)")
   if state.points_in_view.dtype != torch.int16:
     raise ValueError("points_in_view must be int16 (point_state.py:27)")
-  _lib.check(lib.gsr_point_state_add(_p(idx), _p(scale), cols, _p(f32(points.visibility)), _p(f32(points.split_score)),
-                                     _p(f32(points.prune_cost)), M, float(split_alpha), float(prune_alpha),
-                                     _p(state.prune_cost), _p(state.split_score), _p(state.max_scale_px),
-                                     _p(state.points_in_view), _p(state.visibility), _stream()), "gsr_point_state_add")
+  _lib.check(lib.gsr_point_state_add(_p(idx.contiguous()) if idx is not None else None, _p(scale), cols,
+                                     _p(f32(visibility)), _p(f32(split_score)), _p(f32(prune_cost)), M,
+                                     float(split_alpha), float(prune_alpha), _p(state.prune_cost), _p(state.split_score),
+                                     _p(state.max_scale_px), _p(state.points_in_view), _p(state.visibility), _stream()),
+             "gsr_point_state_add")
   return state

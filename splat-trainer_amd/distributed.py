@@ -303,6 +303,54 @@ def evaluate_backward_sharded(params: Sequence[torch.Tensor], cameras: Sequence,
   return gather_point_stats(local_stats, len(cameras), group=group, device=dev)
 
 
+def accumulate_local_stats(points, scale_max: torch.Tensor, visible: torch.Tensor, in_view: torch.Tensor):
+  """Folds one LOCAL camera into the order-independent reductions of the light exchange: running max of the screen
+  scale, summed visibility (= the scene's ``visible`` accumulator, mlp_scene.py:244) and the count of cameras that saw
+  the point (point_state.py:40).  ``idx`` rows are unique per camera."""
+  idx, vis = points.idx, points.visibility
+  scale_max[idx] = torch.maximum(scale_max[idx], points.screen_scale.max(1).values)
+  visible.index_add_(0, idx, vis)
+  in_view.index_add_(0, idx, (vis > 0).to(visible.dtype))
+
+
+def exchange_point_scores(state, local: List[dict], num_cameras: int, num_points: int, group=None, device=None,
+                          counts: Optional[List[List[int]]] = None):
+  """The order-dependent half of the controller statistics: all-gathers every camera's ``split_score`` / ``prune_cost``
+  (+ the row indexes unless every camera sees every point) in ONE packed ``all_gather_into_tensor`` and applies the two
+  ``exp_lerp`` EMAs to ``state`` in camera order on every rank (point_state.py:49-50).  2 (or 3) floats per visible
+  splat and camera instead of the 5 of ``gather_point_stats``; the max / sum / count quantities are order independent
+  and travel as reductions (``CameraShardedStep``)."""
+  ws = dist.get_world_size(group) if dist.is_initialized() else 1
+  if ws == 1:
+    for d in sorted(local, key=lambda d: d["camera"]):
+      state.add_scores(d["idx"], d["split_score"], d["prune_cost"])
+    return state
+  cpr = (num_cameras + ws - 1) // ws
+  dev = device if device is not None else (local[0]["idx"].device if local else None)
+  if dev is None:
+    raise ValueError("exchange_point_scores: pass device= (this rank rendered no camera to take it from)")
+  if counts is None:
+    counts = exchange_counts([(d["camera"], d["idx"].shape[0]) for d in local], cpr, dev, group=group)
+  dense = all(m == num_points for cam, m in counts if cam >= 0)          # nothing culled anywhere: rows are 0..N-1
+  first = 0 if dense else 1
+  L = max(max(m for _, m in counts), 1)
+  mine = torch.zeros(cpr, first + 2, L, dtype=torch.float32, device=dev)
+  for s, d in enumerate(local):
+    m = d["idx"].shape[0]
+    if not dense:
+      mine[s, 0, :m] = d["idx"].to(torch.int32).view(torch.float32)
+    mine[s, first, :m] = d["split_score"].detach().to(torch.float32)
+    mine[s, first + 1, :m] = d["prune_cost"].detach().to(torch.float32)
+  block = torch.empty(ws * cpr, first + 2, L, dtype=torch.float32, device=dev)
+  dist.all_gather_into_tensor(block, mine, group=group)
+  order = sorted((cam, s, m) for s, (cam, m) in enumerate(counts) if cam >= 0)
+  assert [c for c, _, _ in order] == list(range(num_cameras)), "camera shards do not partition the batch"
+  for _, s, m in order:
+    idx = None if dense else block[s, 0, :m].view(torch.int32).long()
+    state.add_scores(idx, block[s, first, :m], block[s, first + 1, :m])
+  return state
+
+
 class CameraShardedStep:
   """One data-parallel batch of the hot path, the way bench.py and the tests run it: this rank renders and
   back-propagates ITS cameras of the batch (camera j -> rank j mod world) with the gradients accumulating straight into
@@ -323,7 +371,10 @@ class CameraShardedStep:
     self.world, self.rank, self.group, self.mode, self.with_stats = max(world_size, 1), rank, group, mode, with_stats
     self.factor = mode == "sh_factor" and self.world > 1
     N = self.params[0].shape[0]
-    self.bucket = GradBucket(self.params[:4] if self.factor else self.params, self.world, extra=N)
+    # extra: [visible accumulator (mlp_scene.py:244) | number of cameras that saw the point] -- both sums, so they ride
+    # in the gradient all-reduce; the screen-scale maximum needs a MAX all-reduce of its own
+    self.bucket = GradBucket(self.params[:4] if self.factor else self.params, self.world, extra=2 * N)
+    self.scale_max = torch.zeros(N, dtype=torch.float32, device=self.params[0].device) if self.world > 1 else None
     self.feature_grad = torch.empty_like(self.params[4]) if self.factor else None
     self.collector = ShFactorCollector() if self.factor else None
     v = self.bucket.views
@@ -337,11 +388,17 @@ class CameraShardedStep:
 
   @property
   def visible(self) -> torch.Tensor:
-    return self.bucket.extra
+    return self.bucket.extra[:self.params[0].shape[0]]
 
-  def run(self, cameras: Sequence, render_backward: Callable) -> List[dict]:
+  def run(self, cameras: Sequence, render_backward: Callable, point_state=None) -> List[dict]:
+    """``point_state`` (controller_math.PointState): the controller's statistics are updated in place for every camera
+    of the batch -- locally with one fused launch per camera on one rank, through the LIGHT exchange on several (max /
+    sum / count as reductions, the two EMA inputs per camera all-gathered and replayed in camera order) -- and nothing
+    is returned.  Without it (and ``with_stats``) the full per-camera statistics of the batch are returned instead."""
     position, feature = self.params[0], self.params[4]
     dev = position.device
+    N = position.shape[0]
+    light = point_state is not None
     mine = shard_cameras(len(cameras), self.rank, self.world)
     if self.factor:
       self.bucket.zero()
@@ -349,15 +406,23 @@ class CameraShardedStep:
       self.bucket.zero(except_views=(4,))
       self.grad_out.feature_uninitialized = True
     local = []
+    if light and self.world > 1:
+      self.scale_max.zero_()
     for j in mine:
       r = render_backward(j, cameras[j], self.grad_out, self.collector)
-      self.bucket.extra.index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
-      if self.with_stats:
+      if light and self.world > 1:
+        accumulate_local_stats(r.points, self.scale_max, self.bucket.extra[:N], self.bucket.extra[N:])
+        local.append(dict(camera=j, idx=r.points.idx, split_score=r.points.split_score, prune_cost=r.points.prune_cost))
+        continue
+      self.bucket.extra[:N].index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
+      if light:
+        point_state.add_rendering(r)                                               # one rank: the reference's own loop
+      elif self.with_stats:
         local.append(point_stats_of(j, r.points))
     if self.world == 1:
-      return local
+      return [] if light else local
     cpr = (len(cameras) + self.world - 1) // self.world
-    counts = exchange_counts([(d["camera"], d["idx"].shape[0]) for d in local] if self.with_stats else
+    counts = exchange_counts([(d["camera"], d["idx"].shape[0]) for d in local] if (self.with_stats or light) else
                              [(j, it[0].shape[0]) for j, it in zip(mine, self.collector.items)] if self.factor else
                              [(j, 0) for j in mine], cpr, dev, group=self.group)
     if self.factor:
@@ -367,6 +432,13 @@ class CameraShardedStep:
                           visible_max=max(m for _, m in counts))
     else:
       self.bucket.all_reduce(group=self.group, mode=self.mode)
+    if light:
+      dist.all_reduce(self.scale_max, op=dist.ReduceOp.MAX, group=self.group)
+      torch.maximum(point_state.max_scale_px, self.scale_max, out=point_state.max_scale_px)
+      point_state.visibility += self.bucket.extra[:N]                 # summed over the ranks by the gradient all-reduce
+      point_state.points_in_view += self.bucket.extra[N:].to(point_state.points_in_view.dtype)
+      exchange_point_scores(point_state, local, len(cameras), N, group=self.group, device=dev, counts=counts)
+      return []
     if not self.with_stats:
       return []
     return gather_point_stats(local, len(cameras), group=self.group, device=dev, counts=counts)

@@ -170,8 +170,26 @@ def _stats_worker(rank, world, port, out_path, num_cameras):
   dense = gather_sh_factors(col, list(range(len(mine))), cpr, n, device="cpu")
   packed = gather_sh_factors(col, list(range(len(mine))), cpr, n, device="cpu", visible_max=max(m for _, m in counts))
   fields = ("prune_cost", "split_score", "max_scale_px", "points_in_view", "visibility")
+  # the LIGHT exchange of CameraShardedStep.run(point_state=...): max / sum / count as reductions, EMA inputs gathered
+  import splat_trainer_amd as sta
+  from splat_trainer_amd.distributed import CameraShardedStep
+  params = [torch.zeros(n, d, requires_grad=True) for d in (3, 3, 4, 1)] + [torch.zeros(n, 3, 4, requires_grad=True)]
+  dp = CameraShardedStep(params, world, rank, mode="all_reduce")
+
+  def fake_render(j, cam, grad_out, collector):
+    d = _camera_stats(j, n)
+    pts = sta.RenderedPoints(idx=d["idx"], depths=torch.zeros(d["idx"].shape[0], 1), opacity=torch.zeros(d["idx"].shape[0]),
+                             screen_scale=torch.stack([d["screen_scale_max"], 0.5 * d["screen_scale_max"]], dim=1),
+                             visibility=d["visibility"], prune_cost=d["prune_cost"], split_score=d["split_score"])
+    return sta.Rendering(image=None, camera=None, points=pts)
+
+  light = PointState.new_zeros(n, "cpu")
+  for _ in range(2):                                             # two batches: the reductions must reset in between
+    assert dp.run(list(range(num_cameras)), fake_render, point_state=light) == []
+  fields = ("prune_cost", "split_score", "max_scale_px", "points_in_view", "visibility")
   torch.save(dict(stats=got, masks=masks, state={f: getattr(state, f) for f in fields}, dense=dense, packed=packed,
-                  counts=counts), f"{out_path}.{rank}")
+                  counts=counts, light={f: getattr(light, f) for f in fields}, visible=dp.visible.clone()),
+             f"{out_path}.{rank}")
   dist.barrier()
   dist.destroy_process_group()
 
@@ -217,3 +235,15 @@ def test_two_rank_point_stats_and_packed_factors(tmp_path, num_cameras):
     assert torch.equal(r["masks"][0], masks[0]) and torch.equal(r["masks"][1], masks[1])
   if num_cameras > 1:
     assert masks[0].any() and masks[1].any()
+  # light exchange, two batches: everything that enters the masks is bit-identical to the sequential loop; the summed
+  # visibility (logged only) is reduced in rank order instead of camera order
+  twice = replay_point_stats(replay_point_stats(PointState.new_zeros(n, "cpu"), seq), seq)
+  for r in (r0, r1):
+    for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view"):
+      assert torch.equal(r["light"][f], getattr(twice, f)), f
+    assert torch.allclose(r["light"]["visibility"], twice.visibility, rtol=1e-6, atol=1e-7)
+    one = replay_point_stats(PointState.new_zeros(n, "cpu"), seq)
+    assert torch.allclose(r["visible"], one.visibility, rtol=1e-6, atol=1e-7)      # the scene's accumulator of one batch
+    m2 = find_split_prune_indexes(PointState(**r["light"]), 0.2, 560, min_views=1, max_scale_px=50.0)
+    want = find_split_prune_indexes(twice, 0.2, 560, min_views=1, max_scale_px=50.0)
+    assert torch.equal(m2[0], want[0]) and torch.equal(m2[1], want[1])

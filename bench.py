@@ -255,6 +255,9 @@ def main():
   timer = renderer.KernelTimer()
   renderer.KERNEL_TIMER = timer
   marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+  import gc
+  gc.collect()
+  gc.disable()                       # no collector pauses inside the timed region (re-enabled right after it)
   t0 = time.perf_counter()
   marks[0].record()
   for i in range(args.steps):
@@ -262,6 +265,7 @@ def main():
     marks[i + 1].record()
   sync()
   elapsed = time.perf_counter() - t0
+  gc.enable()
   renderer.KERNEL_TIMER = None
   per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
   median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else \
@@ -334,6 +338,7 @@ def main():
     out = {
         "metric": "fwd+bwd Gaussians/s", "value": value, "unit": "Gaussians/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "ms_per_step_median": median_ms,
+        "ms_per_step_min_max": [per_step_ms[0], per_step_ms[-1]],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, "
                                f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on",

@@ -230,6 +230,42 @@ def test_config2_full_size_matches_oracle_everywhere():
     assert diff.numel() <= 20, (name, diff.numel())
 
 
+def test_config3_full_size_sampled_tiles_match_oracle():
+  """BASELINE.json configs[2], one camera (3M Gaussians, 1080p, SH degree 3; ~800 pairs on every tile): the projection
+  outputs of all 3M points and the composited image / final T of a fixed sample of 384 tiles against the fp64 oracle
+  (the whole image would take the host minutes; c2 is compared in full above)."""
+  n, w, h = 3_000_000, 1920, 1080
+  g, cams = synthetic.scene_b(n, w, h, sh_degree=3, seed=1, num_cameras=8)
+  cam = cams[0]
+  camd = cam.to("cuda")
+  gd = sta.Gaussians3D(*(t.cuda() for t in (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+  with torch.no_grad():
+    r = sta.render_gaussians(gd, camd, CFG, use_sh=True)
+  dt = torch.float64
+  T, proj = cam.T_camera_world.to(dt), cam.projection.to(dt)
+  idx = oracle.frustum_cull(g.position.to(dt), T, proj, cam.image_size, cam.near_plane, cam.far_plane,
+                            CFG.margin_tiles * CFG.tile_size)
+  assert torch.equal(r.points.idx.cpu(), idx)
+  g2d, depth, sscale = oracle.project(g.position.to(dt), g.log_scaling.to(dt), g.rotation.to(dt), g.alpha_logit.to(dt),
+                                      idx, T, proj, CFG)
+  R = T[:3, :3]
+  feats = oracle.evaluate_sh_at(g.feature.to(dt), g.position.to(dt), idx, -(R.t() @ T[:3, 3]))
+  assert observe("c3 full size 3M 1080p SH3", "depth", r.points.depths, depth, TOL)[0] < TOL
+  assert observe("c3 full size 3M 1080p SH3", "screen_scale", r.points.screen_scale, sscale, TOL)[0] < TOL
+  tiles_x, tiles_y = (w + 15) // 16, (h + 15) // 16
+  gen = torch.Generator().manual_seed(0)
+  tiles = torch.randperm(tiles_x * tiles_y, generator=gen)[:384]
+  out = oracle.rasterize(g2d, depth, feats, (w, h), CFG, tiles=tiles)
+  img, fT = r.image.cpu(), r.final_transmittance.cpu()
+  mask = torch.zeros(h, w, dtype=torch.bool)
+  for t in tiles.tolist():
+    ty, tx = t // tiles_x, t % tiles_x
+    mask[ty * 16:min(ty * 16 + 16, h), tx * 16:min(tx * 16 + 16, w)] = True
+  worst_i, frac_i = observe("c3 full size 3M 1080p SH3", "image (384 tiles)", img[mask], out.image[mask], TOL)
+  worst_t, frac_t = observe("c3 full size 3M 1080p SH3", "final_T (384 tiles)", fT[mask], out.final_T[mask], TOL)
+  assert frac_i <= 1e-4 and frac_t <= 1e-4 and worst_i < 1e-2 and worst_t < 1e-2, (worst_i, frac_i, worst_t, frac_t)
+
+
 @pytest.mark.parametrize("n,w,h,deg", [(3_000_000, 1920, 1080, 3), (10_000_000, 3840, 2160, 3)])
 def test_full_size_properties_large_configs(n, w, h, deg):
   """BASELINE.json configs[2] / configs[4] sizes (3M at 1080p; 10M at 4K with the frustum cull active), one camera.

@@ -70,7 +70,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 13) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 14) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -166,8 +166,10 @@ int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t 
 int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range, void* stream);
 
 /* ---- heavy-tile list segmentation ----------------------------------------------------------------------- */
-/* One wave walks one tile's depth-sorted list serially; a tile with more than heavy_min (>= seg_pairs) pairs is cut
- * into ceil(len / seg_pairs) segments that are composited and back-propagated by one wave each.
+/* One wave walks one tile's depth-sorted list serially.  A tile with more than seg_pairs pairs is cut into segments of
+ * max(seg_pairs, ~len / 32) pairs: its forward walk (still one wave) leaves a checkpoint at every segment end and its
+ * backward pass runs one wave per segment; a tile with more than heavy_min (>= seg_pairs) pairs is composited forward by
+ * one wave per segment as well.
  * gsr_segment_capacity: host-side bound on the number of segments of a frame with O overlaps (sizes the buffers). */
 int64_t gsr_segment_capacity(int64_t O, int32_t seg_pairs, int32_t heavy_min);
 /* tile_seg_out [num_tiles,2], seg_desc_out [capacity,4], seg_total_out [1] (see GsrSegmentsC); seg_total_out must be
@@ -191,8 +193,9 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
 int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
                            const float* pair_vis, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                            const GsrRasterParamsC* params_host, const float* final_T, const int32_t* last,
-                           const float* dL_dimage, float* partial_out,
-                           const GsrSegmentsC* segments_host /* the forward pass's, or NULL */, void* stream);
+                           const float* dL_dimage, const float* image /* the forward output; needed with segments */,
+                           float* partial_out, const GsrSegmentsC* segments_host /* the forward pass's, or NULL */,
+                           void* stream);
 
 /* ---- deterministic per-splat reductions of the per-(tile,splat) partials -------------------------------- */
 /* visibility_out [M] indexed by splat (not rank). */

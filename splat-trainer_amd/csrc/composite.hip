@@ -102,13 +102,16 @@ __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const
 }
 
 // Device view of the segment tables (all NULL / 0 when the caller does not segment).
+#define GSR_SEG_HEAVY 0x80000000u   // tile_seg count word: the tile's FORWARD pass is segmented too (passes A, C, D)
+
 struct SegDev {
-  const uint32_t* tile_seg;    // [num_tiles, 2]: first segment, number of segments (0: light tile)
+  const uint32_t* tile_seg;    // [num_tiles, 2]: first segment, number of segments (0: short tile) | GSR_SEG_HEAVY
   const uint32_t* seg_desc;    // [capacity, 4]: tile, list start, list end, index within the tile
   const uint32_t* seg_total;   // device word: number of segments of this frame
   float* seg_P;                // [capacity, 256]    product of (1 - alpha) over the segment         (pass A)
   float* seg_T;                // [capacity, 256]    T after the segment; < 0: pixel was dead at its entry (pass C)
-  float* seg_C;                // [capacity, C, 256] colour of the segment (C); colour behind it (after D)
+  float* seg_C;                // [capacity, C, 256] colour composited up to the END of the segment (heavy tiles: the
+                               //                    segment's own colour until pass D turns it into that prefix)
   int* seg_last;               // [capacity, 256]
   float* seg_median;           // [capacity, 256] or NULL
 };
@@ -253,14 +256,17 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
                                                            int* __restrict__ last, float* __restrict__ median,
                                                            float* __restrict__ vis_partial,
                                                            float* __restrict__ pair_vis, SegDev seg) {
-  if ((int)blockIdx.x >= num_tiles) {                                // extra blocks: pass A of the heavy tiles
+  if ((int)blockIdx.x >= num_tiles) {                                // extra blocks: pass A of the heavy tiles' segments
     const uint32_t sidx = blockIdx.x - (uint32_t)num_tiles;
-    if (sidx < seg.seg_total[0] && seg.seg_desc[4 * (size_t)sidx + 1] < seg.seg_desc[4 * (size_t)sidx + 2])
-      seg_alpha_pass<C>(sidx, rec, sorted_rank, tiles_x, rp, seg);
+    if (sidx < seg.seg_total[0]) {
+      const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
+      if (d[1] < d[2] && (seg.tile_seg[2 * d[0] + 1] & GSR_SEG_HEAVY)) seg_alpha_pass<C>(sidx, rec, sorted_rank, tiles_x, rp, seg);
+    }
     return;
   }
   const int tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
-  if (seg.tile_seg && seg.tile_seg[2 * tile + 1] != 0u) return;       // heavy tile: passes A, C, D composite it
+  const uint32_t tseg = seg.tile_seg ? seg.tile_seg[2 * tile + 1] : 0u;
+  if (tseg & GSR_SEG_HEAVY) return;                                   // heavy tile: passes A, C, D composite it
   const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
@@ -269,8 +275,32 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
 
   FwdPix<C> px;
   fwd_init<C>(px, px0, py0, W, H);
-  fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, start, end, fx0, fy0, rp, lane, vis_partial,
-                           pair_vis);
+  if (tseg == 0u) {
+    fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, start, end, fx0, fy0, rp, lane, vis_partial,
+                             pair_vis);
+  } else {
+    // A long (but not heavy) tile: still one wave, but the walk pauses at the segment ends and leaves a checkpoint
+    // -- T and the colour composited so far, per pixel -- so that the backward pass can give every segment a wave of
+    // its own (finer work units: its tail and its latency-bound last waves shrink).  4 KB per checkpoint, stores only.
+    const uint32_t first = seg.tile_seg[2 * tile];
+    for (uint32_t j = 0; j < tseg; ++j) {
+      const uint32_t* d = seg.seg_desc + 4 * (size_t)(first + j);
+      fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, d[1], d[2], fx0, fy0, rp, lane, vis_partial,
+                               pair_vis);
+      const size_t o = 256 * (size_t)(first + j) + lane;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int h = p >> 1;
+        seg.seg_T[o + 64 * p] = (p & 1) ? px.T2[h].y : px.T2[h].x;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          seg.seg_C[(size_t)C * 256 * (first + j) + 256 * c + 64 * p + lane] = (p & 1) ? px.col2[h][c].y : px.col2[h][c].x;
+      }
+      const bool live = px.T2[0].x >= rp.T_eps || px.T2[0].y >= rp.T_eps || px.T2[1].x >= rp.T_eps ||
+                        px.T2[1].y >= rp.T_eps;
+      if (__ballot(live) == 0ull) break;            // every pixel saturated: later segments contribute to nothing
+    }
+  }
 
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -301,6 +331,7 @@ __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restri
   if (sidx >= seg.seg_total[0]) return;
   const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
   const int tile = (int)d[0];
+  if (!(seg.tile_seg[2 * tile + 1] & GSR_SEG_HEAVY)) return;          // checkpointed by the one-wave walk instead
   const uint32_t begin = d[1], end = d[2];
   const uint32_t first = seg.tile_seg[2 * tile];
   const int lane = (int)threadIdx.x;
@@ -342,8 +373,9 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
                                                          int* __restrict__ last, float* __restrict__ median,
                                                          SegDev seg) {
   const int tile = (int)blockIdx.x;
-  const uint32_t n = seg.tile_seg[2 * tile + 1];
-  if (n == 0u) return;
+  const uint32_t tseg = seg.tile_seg[2 * tile + 1];
+  if (!(tseg & GSR_SEG_HEAVY)) return;
+  const uint32_t n = tseg & ~GSR_SEG_HEAVY;
   const uint32_t first = seg.tile_seg[2 * tile];
   const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -368,7 +400,11 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
         if (med[p] == 0.f && m != 0.f) med[p] = m;
       }
 #pragma unroll
-      for (int c = 0; c < C; ++c) col[p][c] += seg.seg_C[(size_t)C * 256 * s + 256 * c + 64 * p + lane];
+      for (int c = 0; c < C; ++c) {                    // the segment's own colour becomes the colour up to its end
+        float* cell = seg.seg_C + (size_t)C * 256 * s + 256 * c + 64 * p + lane;
+        col[p][c] += *cell;
+        *cell = col[p][c];
+      }
     }
   }
 #pragma unroll
@@ -382,21 +418,6 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
       last[pix] = lastc[p];
       if (MEDIAN) median[pix] = med[p];
     }
-  }
-  float behind[4][3];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) behind[p][0] = behind[p][1] = behind[p][2] = 0.f;
-  for (uint32_t j = n; j-- > 0u;) {
-    const size_t s = first + j;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        float* cell = seg.seg_C + (size_t)C * 256 * s + 256 * c + 64 * p + lane;
-        const float own = *cell;
-        *cell = behind[p][c];
-        behind[p][c] += own;
-      }
   }
 }
 
@@ -413,9 +434,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
                                                            const float* __restrict__ final_T,
                                                            const int* __restrict__ last,
                                                            const float* __restrict__ dL_dimage,
+                                                           const float* __restrict__ image,
                                                            float* __restrict__ partial, SegDev seg) {
-  // A block walks tile-relative list positions [lo, hi) in reverse: a light tile's whole list, or -- extra blocks of
-  // the launch -- one segment of a heavy tile, entered with that segment's own end state.
+  // A block walks tile-relative list positions [lo, hi) in reverse: a short tile's whole list, or -- extra blocks of
+  // the launch -- one segment of a longer tile, entered with that segment's own end state from the forward pass.
   int tile, lo = 0, seg_hi = 0x7fffffff;
   uint32_t sidx = 0u;
   const bool is_seg = (int)blockIdx.x >= num_tiles;
@@ -429,7 +451,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
     seg_hi = (int)(d[2] - tstart);
   } else {
     tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
-    if (seg.tile_seg && seg.tile_seg[2 * tile + 1] != 0u) return;     // heavy tile: its segments handle it
+    if (seg.tile_seg && seg.tile_seg[2 * tile + 1] != 0u) return;     // segmented tile: its segment blocks handle it
   }
   const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -466,7 +488,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
       for (int c = 0; c < C; ++c) {
         const float gv = dL_dimage[pix * C + c];
         if (p & 1) g2[h][c].y = gv; else g2[h][c].x = gv;
-        if (is_seg) gb = fmaf(gv, seg.seg_C[(size_t)C * 256 * sidx + 256 * c + 64 * p + lane], gb);
+        // colour behind the segment = final colour - colour composited up to the segment's end
+        if (is_seg) gb = fmaf(gv, image[pix * C + c] - seg.seg_C[(size_t)C * 256 * sidx + 256 * c + 64 * p + lane], gb);
       }
       if (p & 1) ga2[h].y = gb; else ga2[h].x = gb;   // g . (colour behind the segment); 0 for a whole tile
     }
@@ -592,10 +615,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
   }
 }
 
-// Plans the frame, one thread per tile: a tile with more than `heavy_min` pairs is cut into ceil(len / seg_pairs)
-// segments of (almost) equal length, numbered consecutively from a slot range the tile reserves with one integer atomic
-// on the (zero-initialised) segment counter.  Which range a tile gets depends on arrival order; nothing else does: a
-// tile's segments are contiguous and in list order, and every result is a function of that order alone.
+// Plans the frame, one thread per tile.  A tile longer than `seg_pairs` is cut into segments of seg_t = max(seg_pairs,
+// ceil(len / 32) rounded up to 4) pairs (the last one shorter; at most ~32 per tile), numbered consecutively from a slot
+// range the tile reserves with one integer atomic on the (zero-initialised) segment counter; a tile longer than
+// `heavy_min` is flagged GSR_SEG_HEAVY: its forward pass is segmented too.  Which range a tile gets depends on arrival
+// order; nothing else does: a tile's segments are contiguous and in list order, every result is a function of that alone.
 __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __restrict__ tile_range, int num_tiles,
                                                            uint32_t seg_pairs, uint32_t heavy_min, uint32_t capacity,
                                                            uint32_t* __restrict__ tile_seg,
@@ -604,12 +628,13 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (t >= num_tiles) return;
   const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
-  uint32_t n = len > heavy_min ? (len + seg_pairs - 1) / seg_pairs : 0u;
+  const uint32_t seg_t = max(seg_pairs, (((len + 31u) / 32u) + 3u) & ~3u);
+  uint32_t n = len > seg_pairs ? (len + seg_t - 1) / seg_t : 0u;
   uint32_t at = 0u;
   if (n) {
     at = atomicAdd(seg_total, n);
     if (at + n > capacity) {                       // cannot happen with the host's bound; stay in range regardless:
-      for (uint32_t j = at; j < capacity; ++j) {   // the tile stays light and its reserved slots become empty segments
+      for (uint32_t j = at; j < capacity; ++j) {   // the tile stays unsegmented and its reserved slots become empty segments
         uint32_t* d = seg_desc + 4 * (size_t)j;
         d[0] = (uint32_t)t; d[1] = a; d[2] = a; d[3] = 0u;
       }
@@ -617,16 +642,10 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
     }
   }
   tile_seg[2 * t] = at;
-  tile_seg[2 * t + 1] = n;
-  if (n) {
-    const uint32_t base = len / n, rem = len % n;
-    uint32_t b = a;
-    for (uint32_t j = 0; j < n; ++j) {
-      const uint32_t e = b + base + (j < rem ? 1u : 0u);
-      uint32_t* d = seg_desc + 4 * (size_t)(at + j);
-      d[0] = (uint32_t)t; d[1] = b; d[2] = e; d[3] = j;
-      b = e;
-    }
+  tile_seg[2 * t + 1] = n | ((n && len > heavy_min) ? GSR_SEG_HEAVY : 0u);
+  for (uint32_t j = 0; j < n; ++j) {
+    uint32_t* d = seg_desc + 4 * (size_t)(at + j);
+    d[0] = (uint32_t)t; d[1] = a + j * seg_t; d[2] = min(a + (j + 1) * seg_t, a + len); d[3] = j;
   }
 }
 
@@ -655,8 +674,8 @@ extern "C" {
 
 int64_t gsr_segment_capacity(int64_t O, int32_t seg_pairs, int32_t heavy_min) {
   if (O <= 0 || seg_pairs <= 0 || heavy_min < seg_pairs) return 0;
-  // a heavy tile of len pairs (len > heavy_min) yields ceil(len / seg_pairs) <= len / seg_pairs + 1 segments
-  return O / seg_pairs + O / ((int64_t)heavy_min + 1) + 1;
+  // a tile of len pairs (len > seg_pairs) yields at most ceil(len / seg_pairs) <= len / seg_pairs + 1 segments
+  return O / seg_pairs + O / ((int64_t)seg_pairs + 1) + 1;
 }
 
 int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs, int32_t heavy_min,
@@ -721,20 +740,20 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
 int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
                            const float* pair_vis, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                            const GsrRasterParamsC* params_host, const float* final_T, const int32_t* last,
-                           const float* dL_dimage, float* partial_out, const GsrSegmentsC* segments_host,
-                           void* stream_) {
+                           const float* dL_dimage, const float* image, float* partial_out,
+                           const GsrSegmentsC* segments_host, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16 || C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
   if (!tile_range || !final_T || !last || !dL_dimage) return GSR_ERR_INVALID_ARGUMENT;
-  if (!seg_ok(segments_host, false)) return GSR_ERR_INVALID_ARGUMENT;
+  if (!seg_ok(segments_host, false) || (segments_host && !image)) return GSR_ERR_INVALID_ARGUMENT;
   const int tx = (W + 15) / 16, ty = (H + 15) / 16, nt = tx * ty;
   const GsrRasterParams rp = to_params(params_host);
   const SegDev seg = to_segdev(segments_host);
   const int grid = nt + (segments_host ? (int)segments_host->capacity : 0);
-  if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out, seg);
-  else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out, seg);
-  else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, partial_out, seg);
+  if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
+  else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
+  else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -33,9 +33,10 @@ class RasterConfig:
   aa_blur: float = 0.3                # anti-alias filter variance (px^2) used when antialias=True
   compute_visibility: bool = False    # fill points.visibility (sum_pixels T*alpha) in forward
   compute_point_heuristic: bool = False  # fill prune_cost / split_score in backward
-  segment_pairs: int = 256            # heavy tiles: list segments of at most this many (tile, splat) pairs; 0 = off
-  segment_min_pairs: int = 0          # a tile is heavy (its list is segmented) above this many pairs; 0 = chosen per
-                                      # frame from the overlap count (renderer._segment_thresholds)
+  segment_pairs: int = -1             # list segments of a tile: length in (tile, splat) pairs; -1 = chosen per frame,
+                                      # 0 = no segmentation at all (renderer._segment_thresholds)
+  segment_min_pairs: int = 0          # a tile is heavy (its FORWARD pass is segmented too) above this many pairs;
+                                      # 0 = chosen per frame from the overlap count
 
   @property
   def transmittance_eps(self) -> float:

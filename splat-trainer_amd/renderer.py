@@ -224,7 +224,7 @@ class _RasterState:
   __slots__ = ("M", "O", "C", "W", "H", "params", "rec", "order", "count", "offsets", "sorted_rank",
                "sorted_inst", "tile_range", "vis_partial", "pair_vis", "final_T", "last", "median", "visibility",
                "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad",
-               "segments", "segment_buffers", "seg_pairs", "seg_min")
+               "segments", "segment_buffers", "seg_pairs", "seg_min", "image")
 
 
 def _u32(n: int, device) -> torch.Tensor:
@@ -245,16 +245,28 @@ def _launch_depth_order(depth: torch.Tensor, M: int) -> torch.Tensor:
   return vals_b if where == 1 else vals_a
 
 
-def _segment_thresholds(seg_pairs: int, seg_min: int, O: int):
-  """(segment length, heavy-tile threshold) of a frame.  Cutting a tile's list only pays when that tile would otherwise
-  outlast the rest of the launch: the forward pass of a segmented tile costs an extra alpha-product pass, so a frame
-  whose tiles are all equally long (3M splats at 1080p: ~800 pairs on EVERY tile) must not be segmented at all.  A
-  lone wave walks ~6 pairs per microsecond while the balanced launch takes ~(40 + 0.11 O / 1000) us (measured K6 fit),
-  so a tile is heavy above about half of what one wave can walk in that time; segments are half a threshold long."""
-  if seg_min > 0:
-    return seg_pairs, max(seg_min, seg_pairs)
-  heavy = max(2 * seg_pairs, 120 + O // 2900)
-  return max(seg_pairs, heavy // 2), heavy
+def _segment_thresholds(seg_pairs: int, seg_min: int, O: int, num_tiles: int, needs_grad: bool):
+  """(segment length, heavy-tile threshold) of a frame; explicit config values win, negative / zero mean automatic.
+
+  Heavy threshold: cutting a tile's FORWARD walk only pays when that tile would otherwise outlast the rest of the
+  launch -- a segmented forward pass costs an extra alpha-product pass, so a frame whose tiles are all equally long
+  (3M splats at 1080p: ~800 pairs on EVERY tile) must not be cut there.  A lone wave walks ~6 pairs per microsecond
+  while the balanced launch takes ~(40 + 0.11 O / 1000) us (measured K6 fit), so a tile is heavy above about half of
+  what one wave can walk in that time.
+
+  Segment length: the BACKWARD pass is cheaper to split -- the one-wave forward walk just stores a 4 KB checkpoint per
+  segment end -- and gains from finer work units (measured: K7 -9 % on c2 at 64-pair segments, -12 % on c3 at 256), so
+  with gradients on every tile is cut into about three segments (mean list length / 3, within [64, 256], multiple of
+  4); without gradients only heavy tiles are cut, into segments half a threshold long."""
+  heavy = seg_min if seg_min > 0 else max(512, 120 + O // 2900)
+  if seg_pairs > 0:
+    seg = seg_pairs
+  elif needs_grad:
+    seg = min(256, max(64, (O // max(3 * num_tiles, 1)) & ~3))
+  else:
+    seg = max(256, (heavy // 2) & ~3)
+  seg = max(4, (seg + 3) & ~3) if seg_pairs <= 0 else seg
+  return seg, max(heavy, seg)
 
 
 def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream, seg_total: torch.Tensor):
@@ -263,10 +275,10 @@ def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream, seg_
   The tables are sized from a host-side bound on the segment count, so no extra sync is needed.  ``seg_total``: a
   zero-initialised device word (the plan kernel's tiles reserve their segment slots on it)."""
   st.segment_buffers = None
-  if st.seg_pairs <= 0:
+  if st.seg_pairs == 0:
     return None
   lib = _lib.load()
-  seg_pairs, seg_min = _segment_thresholds(st.seg_pairs, st.seg_min, O)
+  seg_pairs, seg_min = _segment_thresholds(st.seg_pairs, st.seg_min, O, num_tiles, st.needs_grad)
   cap = int(lib.gsr_segment_capacity(O, seg_pairs, seg_min))
   if cap <= 0:
     return None
@@ -390,6 +402,7 @@ class _RasterFn(torch.autograd.Function):
   def forward(ctx, g2d, feats, depth, st: _RasterState, order):
     g, f, d = _f32c(g2d), _f32c(feats), _f32c(depth).reshape(-1)
     image = _bin_and_composite(g, f, d, st, need_vis_partial=st.compute_visibility or st.needs_grad, order=order)
+    st.image = image.detach() if st.needs_grad else None     # segment blocks of the backward pass need the final colour
     ctx.st = st
     ctx.in_dtypes = (g2d.dtype, feats.dtype)      # e.g. fp16 colours from an autocast MLP (mlp_scene.py:362)
     return image
@@ -415,7 +428,8 @@ class _RasterFn(torch.autograd.Function):
       _lib.check(lib.gsr_composite_backward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
                                             _ptr(st.pair_vis), _ptr(st.tile_range), st.W, st.H, st.C,
                                             C.byref(st.params), _ptr(st.final_T), _ptr(st.last), _ptr(dimg),
-                                            _ptr(partial), _seg_ref(st), stream), "gsr_composite_backward")
+                                            _ptr(st.image), _ptr(partial), _seg_ref(st), stream),
+                 "gsr_composite_backward")
       if timer is not None:
         timer.end("composite_backward")
       # prune_cost / split_score are written straight into the tensors the Rendering already holds

@@ -32,6 +32,26 @@ def test_forced_segments_match_oracle(seg, sh_degree, w, h, n):
   assert rel_err(hip["median"], orc["median"]) < 1e-5
 
 
+@pytest.mark.parametrize("seg", [4, 7, 32])
+def test_checkpointed_backward_segments_match_oracle(seg):
+  """Tiles longer than `seg` but below the heavy threshold: the forward pass stays one wave per tile and leaves a T /
+  colour checkpoint at every segment end; the backward pass runs one wave per segment from those checkpoints (colour
+  behind a segment = final colour - colour up to its end)."""
+  g, cam = small_scene(900, 50, 37, sh_degree=2, seed=13, sigma_px=3.0)
+  cfg = _cfg(seg, seg_min=10 ** 9)
+  hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True)
+  orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True)
+  compare_to_oracle(f"checkpointed backward seg={seg}", hip, orc, 1e-4)
+  whole = hip_render_and_grads(g, cam, _cfg(0), use_sh=True, want_median=True)
+  for k in ("image", "final_T", "visibility", "median"):
+    assert torch.equal(hip[k], whole[k]), k          # the forward pass is the same walk, bit for bit
+  again = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True)
+  for k in KEYS:
+    worst, _ = observe(f"checkpointed backward seg={seg} vs one wave per tile", k, hip[k], whole[k], 1e-5)
+    assert worst < 2e-5, (k, worst)
+    assert torch.equal(hip[k], again[k]), k
+
+
 def test_segmented_equals_unsegmented_to_rounding_and_is_reproducible():
   g, cam = small_scene(1500, 96, 80, sh_degree=1, seed=5, sigma_px=3.0)
   whole = hip_render_and_grads(g, cam, _cfg(0), use_sh=True, want_median=True)

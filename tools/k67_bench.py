@@ -25,7 +25,7 @@ else:
   cam = cams[0]
 g, cam = g.to("cuda"), cam.to("cuda")
 cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True,
-                       segment_pairs=int(os.environ.get("SEG_PAIRS", "256")), segment_min_pairs=int(os.environ.get("SEG_MIN", "0")))
+                       segment_pairs=int(os.environ.get("SEG_PAIRS", "-1")), segment_min_pairs=int(os.environ.get("SEG_MIN", "0")))
 params = [t.requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
 scene = sta.Gaussians3D(position=params[0], log_scaling=params[1], rotation=params[2], alpha_logit=params[3], feature=params[4])
 

@@ -64,13 +64,12 @@ typedef struct GsrSegmentsC {
   const uint32_t* seg_total;  /* device word: segments of this frame (<= capacity) */
   int64_t capacity;           /* from gsr_segment_capacity */
   float* seg_P;               /* [capacity,256] */
-  float* seg_T;               /* [capacity,256] */
-  float* seg_C;               /* [capacity,C,256] */
+  float* seg_TC;              /* [capacity,256,4], 16-byte aligned: (T, c0, c1, c2) per pixel slot */
   int32_t* seg_last;          /* [capacity,256] */
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 14) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 15) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */

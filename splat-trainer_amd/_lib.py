@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class GsrRasterParamsC(C.Structure):
@@ -23,7 +23,7 @@ class GsrRasterParamsC(C.Structure):
 
 class GsrSegmentsC(C.Structure):
   _fields_ = [("tile_seg", C.c_void_p), ("seg_desc", C.c_void_p), ("seg_total", C.c_void_p), ("capacity", C.c_int64),
-              ("seg_P", C.c_void_p), ("seg_T", C.c_void_p), ("seg_C", C.c_void_p), ("seg_last", C.c_void_p),
+              ("seg_P", C.c_void_p), ("seg_TC", C.c_void_p), ("seg_last", C.c_void_p),
               ("seg_median", C.c_void_p)]
 
 

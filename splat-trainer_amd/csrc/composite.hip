@@ -109,9 +109,9 @@ struct SegDev {
   const uint32_t* seg_desc;    // [capacity, 4]: tile, list start, list end, index within the tile
   const uint32_t* seg_total;   // device word: number of segments of this frame
   float* seg_P;                // [capacity, 256]    product of (1 - alpha) over the segment         (pass A)
-  float* seg_T;                // [capacity, 256]    T after the segment; < 0: pixel was dead at its entry (pass C)
-  float* seg_C;                // [capacity, C, 256] colour composited up to the END of the segment (heavy tiles: the
-                               //                    segment's own colour until pass D turns it into that prefix)
+  float4* seg_TC;              // [capacity, 256] (T, c0, c1, c2) per pixel slot: T after the segment (< 0: the pixel was
+                               //   dead at its entry, pass C) and the colour composited up to the END of the segment
+                               //   (heavy tiles: the segment's own colour until pass D turns it into that prefix)
   int* seg_last;               // [capacity, 256]
   float* seg_median;           // [capacity, 256] or NULL
 };
@@ -279,22 +279,21 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
     fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, start, end, fx0, fy0, rp, lane, vis_partial,
                              pair_vis);
   } else {
-    // A long (but not heavy) tile: still one wave, but the walk pauses at the segment ends and leaves a checkpoint
-    // -- T and the colour composited so far, per pixel -- so that the backward pass can give every segment a wave of
-    // its own (finer work units: its tail and its latency-bound last waves shrink).  4 KB per checkpoint, stores only.
+    // A long (but not heavy) tile is still walked by this one wave, but the walk pauses at the segment ends and leaves
+    // a checkpoint -- (T, colour composited so far) per pixel, one 16-byte store each -- so that the backward pass can
+    // give every segment a wave of its own (finer work units: its tail and its latency-bound last waves shrink).
+    // (Kept as a second copy of the walk: the one-segment form of this loop costs the short-tile path 10-20 %.)
     const uint32_t first = seg.tile_seg[2 * tile];
     for (uint32_t j = 0; j < tseg; ++j) {
       const uint32_t* d = seg.seg_desc + 4 * (size_t)(first + j);
       fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, d[1], d[2], fx0, fy0, rp, lane, vis_partial,
                                pair_vis);
-      const size_t o = 256 * (size_t)(first + j) + lane;
+      float4* out = seg.seg_TC + 256 * (size_t)(first + j) + lane;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int h = p >> 1;
-        seg.seg_T[o + 64 * p] = (p & 1) ? px.T2[h].y : px.T2[h].x;
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-          seg.seg_C[(size_t)C * 256 * (first + j) + 256 * c + 64 * p + lane] = (p & 1) ? px.col2[h][c].y : px.col2[h][c].x;
+        out[64 * p] = (p & 1) ? make_float4(px.T2[h].y, px.col2[h][0].y, px.col2[h][1].y, px.col2[h][2].y)
+                              : make_float4(px.T2[h].x, px.col2[h][0].x, px.col2[h][1].x, px.col2[h][2].x);
       }
       const bool live = px.T2[0].x >= rp.T_eps || px.T2[0].y >= rp.T_eps || px.T2[1].x >= rp.T_eps ||
                         px.T2[1].y >= rp.T_eps;
@@ -355,12 +354,10 @@ __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restri
   for (int p = 0; p < 4; ++p) {
     const int h = p >> 1;
     const float t = (p & 1) ? px.T2[h].y : px.T2[h].x;
-    seg.seg_T[o + 64 * p] = alive[p] ? t : -1.f;
+    seg.seg_TC[o + 64 * p] = (p & 1) ? make_float4(alive[p] ? t : -1.f, px.col2[h][0].y, px.col2[h][1].y, px.col2[h][2].y)
+                                     : make_float4(alive[p] ? t : -1.f, px.col2[h][0].x, px.col2[h][1].x, px.col2[h][2].x);
     seg.seg_last[o + 64 * p] = px.lastc[p];
     if (MEDIAN) seg.seg_median[o + 64 * p] = (p & 1) ? px.med2[h].y : px.med2[h].x;
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-      seg.seg_C[(size_t)C * 256 * sidx + 256 * c + 64 * p + lane] = (p & 1) ? px.col2[h][c].y : px.col2[h][c].x;
   }
 }
 
@@ -391,20 +388,16 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
     const size_t s = first + j, o = 256 * s + lane;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const float t = seg.seg_T[o + 64 * p];
-      if (t >= 0.f) T[p] = t;
+      const float4 tc = seg.seg_TC[o + 64 * p];
+      if (tc.x >= 0.f) T[p] = tc.x;
       const int l = seg.seg_last[o + 64 * p];
       if (l != 0) lastc[p] = l;
       if (MEDIAN) {
         const float m = seg.seg_median[o + 64 * p];
         if (med[p] == 0.f && m != 0.f) med[p] = m;
       }
-#pragma unroll
-      for (int c = 0; c < C; ++c) {                    // the segment's own colour becomes the colour up to its end
-        float* cell = seg.seg_C + (size_t)C * 256 * s + 256 * c + 64 * p + lane;
-        col[p][c] += *cell;
-        *cell = col[p][c];
-      }
+      col[p][0] += tc.y; col[p][1] += tc.z; col[p][2] += tc.w;      // the segment's own colour becomes the colour up to its end
+      seg.seg_TC[o + 64 * p] = make_float4(tc.x, col[p][0], col[p][1], col[p][2]);
     }
   }
 #pragma unroll
@@ -477,10 +470,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
       float t = final_T[pix];
+      float4 tc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (is_seg) {                                   // T after this segment (dead-at-entry pixels never contribute)
-        t = seg.seg_T[256 * (size_t)sidx + 64 * p + lane];
-        t = t < 0.f ? 1.f : t;
+        tc = seg.seg_TC[256 * (size_t)sidx + 64 * p + lane];
+        t = tc.x < 0.f ? 1.f : tc.x;
       }
+      const float upto[3] = {tc.y, tc.z, tc.w};
       if (p & 1) T2[h].y = t; else T2[h].x = t;
       lastc[p] = last[pix];
       float gb = 0.f;
@@ -489,7 +484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
         const float gv = dL_dimage[pix * C + c];
         if (p & 1) g2[h][c].y = gv; else g2[h][c].x = gv;
         // colour behind the segment = final colour - colour composited up to the segment's end
-        if (is_seg) gb = fmaf(gv, image[pix * C + c] - seg.seg_C[(size_t)C * 256 * sidx + 256 * c + 64 * p + lane], gb);
+        if (is_seg) gb = fmaf(gv, image[pix * C + c] - upto[c], gb);
       }
       if (p & 1) ga2[h].y = gb; else ga2[h].x = gb;   // g . (colour behind the segment); 0 for a whole tile
     }
@@ -615,10 +610,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
   }
 }
 
-// Plans the frame, one thread per tile.  A tile longer than `seg_pairs` is cut into segments of seg_t = max(seg_pairs,
-// ceil(len / 32) rounded up to 4) pairs (the last one shorter; at most ~32 per tile), numbered consecutively from a slot
-// range the tile reserves with one integer atomic on the (zero-initialised) segment counter; a tile longer than
-// `heavy_min` is flagged GSR_SEG_HEAVY: its forward pass is segmented too.  Which range a tile gets depends on arrival
+// Plans the frame, one thread per tile.  A tile longer than `seg_pairs` is cut into segments (the last one shorter),
+// numbered consecutively from a slot range the tile reserves with one integer atomic on the (zero-initialised) segment
+// counter; a tile longer than `heavy_min` is flagged GSR_SEG_HEAVY: its forward pass is segmented too.  Which range a tile gets depends on arrival
 // order; nothing else does: a tile's segments are contiguous and in list order, every result is a function of that alone.
 __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __restrict__ tile_range, int num_tiles,
                                                            uint32_t seg_pairs, uint32_t heavy_min, uint32_t capacity,
@@ -628,7 +622,11 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (t >= num_tiles) return;
   const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
-  const uint32_t seg_t = max(seg_pairs, (((len + 31u) / 32u) + 3u) & ~3u);
+  // a heavy tile's segments are also FORWARD work units (alpha-product pass + a prologue over the preceding segments):
+  // about 256 pairs each and at most ~128 per tile; a long tile's segments are only checkpoints: seg_pairs each
+  const bool heavy = len > heavy_min;
+  const uint32_t seg_heavy = max(seg_pairs, min(256u, (heavy_min / 2u) & ~3u));
+  const uint32_t seg_t = heavy ? max(seg_heavy, (((len + 127u) / 128u) + 3u) & ~3u) : seg_pairs;
   uint32_t n = len > seg_pairs ? (len + seg_t - 1) / seg_t : 0u;
   uint32_t at = 0u;
   if (n) {
@@ -642,7 +640,7 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
     }
   }
   tile_seg[2 * t] = at;
-  tile_seg[2 * t + 1] = n | ((n && len > heavy_min) ? GSR_SEG_HEAVY : 0u);
+  tile_seg[2 * t + 1] = n | ((n && heavy) ? GSR_SEG_HEAVY : 0u);
   for (uint32_t j = 0; j < n; ++j) {
     uint32_t* d = seg_desc + 4 * (size_t)(at + j);
     d[0] = (uint32_t)t; d[1] = a + j * seg_t; d[2] = min(a + (j + 1) * seg_t, a + len); d[3] = j;
@@ -653,10 +651,10 @@ inline SegDev to_segdev(const GsrSegmentsC* sg) {
   SegDev d;
   if (sg) {
     d.tile_seg = sg->tile_seg; d.seg_desc = sg->seg_desc; d.seg_total = sg->seg_total; d.seg_P = sg->seg_P;
-    d.seg_T = sg->seg_T; d.seg_C = sg->seg_C; d.seg_last = sg->seg_last; d.seg_median = sg->seg_median;
+    d.seg_TC = reinterpret_cast<float4*>(sg->seg_TC); d.seg_last = sg->seg_last; d.seg_median = sg->seg_median;
   } else {
-    d.tile_seg = nullptr; d.seg_desc = nullptr; d.seg_total = nullptr; d.seg_P = nullptr; d.seg_T = nullptr;
-    d.seg_C = nullptr; d.seg_last = nullptr; d.seg_median = nullptr;
+    d.tile_seg = nullptr; d.seg_desc = nullptr; d.seg_total = nullptr; d.seg_P = nullptr; d.seg_TC = nullptr;
+    d.seg_last = nullptr; d.seg_median = nullptr;
   }
   return d;
 }
@@ -664,7 +662,7 @@ inline SegDev to_segdev(const GsrSegmentsC* sg) {
 inline bool seg_ok(const GsrSegmentsC* sg, bool median) {
   if (!sg) return true;
   if (sg->capacity <= 0) return false;
-  return sg->tile_seg && sg->seg_desc && sg->seg_total && sg->seg_P && sg->seg_T && sg->seg_C && sg->seg_last &&
+  return sg->tile_seg && sg->seg_desc && sg->seg_total && sg->seg_P && sg->seg_TC && sg->seg_last &&
          (!median || sg->seg_median);
 }
 

@@ -377,7 +377,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 14; }
+int gsr_abi_version(void) { return 15; }
 
 const char* gsr_error_string(int code) {
   switch (code) {

@@ -255,14 +255,15 @@ def _segment_thresholds(seg_pairs: int, seg_min: int, O: int, num_tiles: int, ne
   what one wave can walk in that time.
 
   Segment length: the BACKWARD pass is cheaper to split -- the one-wave forward walk just stores a 4 KB checkpoint per
-  segment end -- and gains from finer work units (measured: K7 -9 % on c2 at 64-pair segments, -12 % on c3 at 256), so
-  with gradients on every tile is cut into about three segments (mean list length / 3, within [64, 256], multiple of
-  4); without gradients only heavy tiles are cut, into segments half a threshold long."""
+  segment end (+10 % on K6 at three checkpoints per tile) -- and gains from finer work units (measured: K7 -5 % on c2 at
+  64-pair segments with K6 paying as much; K7 -13 % at 256-pair and -20 % at 128-pair segments on c3 for +2..4 % on K6),
+  so with gradients on a tile is cut into about six segments (mean list length / 6, within [64, 256], multiple of 4);
+  without gradients only heavy tiles are cut, into segments half a threshold long."""
   heavy = seg_min if seg_min > 0 else max(512, 120 + O // 2900)
   if seg_pairs > 0:
     seg = seg_pairs
   elif needs_grad:
-    seg = min(256, max(64, (O // max(3 * num_tiles, 1)) & ~3))
+    seg = min(256, max(64, (O // max(6 * num_tiles, 1) + 3) & ~3))
   else:
     seg = max(256, (heavy // 2) & ~3)
   seg = max(4, (seg + 3) & ~3) if seg_pairs <= 0 else seg
@@ -286,14 +287,14 @@ def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream, seg_
   tile_seg, seg_desc = tables[:2 * num_tiles], tables[2 * num_tiles:]
   _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, seg_pairs, seg_min, cap, _ptr(tile_seg),
                                   _ptr(seg_desc), _ptr(seg_total), stream), "gsr_segment_plan")
-  planes = 2 + st.C + (1 if st.want_median else 0)
+  planes = 5 + (1 if st.want_median else 0)                       # (T, c0, c1, c2) interleaved + alpha products (+ median)
   pix = torch.empty(planes * cap * 256, dtype=torch.float32, device=dev)
   seg_last = torch.empty(cap * 256, dtype=torch.int32, device=dev)
-  seg_P, seg_T, seg_C = pix[:cap * 256], pix[cap * 256:2 * cap * 256], pix[2 * cap * 256:(2 + st.C) * cap * 256]
-  seg_med = pix[(2 + st.C) * cap * 256:] if st.want_median else None
+  seg_TC, seg_P = pix[:4 * cap * 256], pix[4 * cap * 256:5 * cap * 256]
+  seg_med = pix[5 * cap * 256:] if st.want_median else None
   st.segment_buffers = (tables, pix, seg_last, seg_total)           # kept alive until backward has run
   return _lib.GsrSegmentsC(tile_seg.data_ptr(), seg_desc.data_ptr(), seg_total.data_ptr(), cap, seg_P.data_ptr(),
-                           seg_T.data_ptr(), seg_C.data_ptr(), seg_last.data_ptr(),
+                           seg_TC.data_ptr(), seg_last.data_ptr(),
                            seg_med.data_ptr() if seg_med is not None else None)
 
 

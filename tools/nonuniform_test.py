@@ -7,7 +7,7 @@ import splat_trainer_amd as sta
 from splat_trainer_amd import synthetic, renderer
 W, H, n = 1920, 1080, 500_000
 import itertools
-CFGS = {"segmented (256/512)": sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True),
+CFGS = {"segmented (automatic thresholds)": sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True),
         "one wave per tile": sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True, segment_pairs=0)}
 for (frac, region), (cfg_name, cfg) in itertools.product([(0.0, 1.0), (0.3, 0.2), (0.5, 0.1), (0.5, 0.05)], CFGS.items()):
   g, cam = synthetic.scene_a(n, W, H, sh_degree=0, seed=0)

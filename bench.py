@@ -249,15 +249,22 @@ def main():
     torch.cuda.synchronize()
 
   copy_gbs = measure_copy_bandwidth(dev) if rank == 0 else None
-  for _ in range(args.warmup):
-    step()
-  sync()
-  timer = renderer.KernelTimer()
-  renderer.KERNEL_TIMER = timer
-  marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
   import gc
   gc.collect()
   gc.disable()                       # no collector pauses inside the timed region (re-enabled right after it)
+  # Untimed preparation: the device needs ~30 steps after an idle period before its clocks and the allocator reach a
+  # steady state (per-step times fall monotonically from 1.30 to 1.12 ms over the first 25 steps on c2, BENCH_TRACE_STEPS=1),
+  # so the W warm-up steps the caller asked for are preceded by enough extra untimed ones to make 30 in total.
+  prewarm = max(0, 30 - args.warmup)
+  for _ in range(prewarm + args.warmup):
+    step()
+  timer = renderer.KernelTimer()
+  timer.reserve(4 * args.steps * max(len(batch) // max(world, 1), 1) + 8)   # events exist before the timed region starts
+  marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+  for m in marks:
+    m.record()
+  sync()
+  renderer.KERNEL_TIMER = timer
   t0 = time.perf_counter()
   marks[0].record()
   for i in range(args.steps):
@@ -267,7 +274,10 @@ def main():
   elapsed = time.perf_counter() - t0
   gc.enable()
   renderer.KERNEL_TIMER = None
-  per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+  step_trace = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+  if os.environ.get("BENCH_TRACE_STEPS") == "1" and rank == 0:
+    print("per-step ms:", " ".join(f"{t:.3f}" for t in step_trace), file=sys.stderr, flush=True)
+  per_step_ms = sorted(step_trace)
   median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else \
       0.5 * (per_step_ms[len(per_step_ms) // 2 - 1] + per_step_ms[len(per_step_ms) // 2])
   if world > 1:
@@ -337,7 +347,8 @@ def main():
                        line(alg_bytes_step, median_ms)}})
     out = {
         "metric": "fwd+bwd Gaussians/s", "value": value, "unit": "Gaussians/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "ms_per_step_median": median_ms,
+        "steps": args.steps, "warmup": args.warmup, "untimed_prewarm_steps": prewarm, "ms_per_step": step_ms,
+        "ms_per_step_median": median_ms,
         "ms_per_step_min_max": [per_step_ms[0], per_step_ms[-1]],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, "

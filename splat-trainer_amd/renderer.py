@@ -38,16 +38,26 @@ class KernelTimer:
   def __init__(self):
     self.events = {}
     self._open = {}
+    self._pool = []
+
+  def reserve(self, n: int):
+    """Creates ``n`` events up front (the runtime materialises an event at its first record, in pool-sized batches:
+    a few hundred microseconds that would otherwise land inside somebody's timed step)."""
+    for _ in range(n):
+      e = torch.cuda.Event(enable_timing=True)
+      e.record(torch.cuda.current_stream())
+      self._pool.append(e)
+
+  def _event(self):
+    e = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+    e.record(torch.cuda.current_stream())
+    return e
 
   def begin(self, name: str):
-    e = torch.cuda.Event(enable_timing=True)
-    e.record(torch.cuda.current_stream())
-    self._open[name] = e
+    self._open[name] = self._event()
 
   def end(self, name: str):
-    e = torch.cuda.Event(enable_timing=True)
-    e.record(torch.cuda.current_stream())
-    self.events.setdefault(name, []).append((self._open.pop(name), e))
+    self.events.setdefault(name, []).append((self._open.pop(name), self._event()))
 
   def summary(self) -> dict:
     """name -> (launches, average milliseconds).  Synchronises."""

@@ -417,6 +417,12 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
 #ifndef GSR_K7_WAVES
 #define GSR_K7_WAVES 6
 #endif
+#ifndef GSR_K7_SEGMAP             // segment block -> segment: 0 identity, 1 contiguous range per XCD, 2 grouped
+#define GSR_K7_SEGMAP 2
+#endif
+#ifndef GSR_K7_SEG_GROUP_LOG2
+#define GSR_K7_SEG_GROUP_LOG2 5
+#endif
 template <int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES, GSR_K7_WAVES))) void composite_bwd_kernel(const float* __restrict__ rec,
                                                            const uint32_t* __restrict__ sorted_rank,
@@ -436,7 +442,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
   const bool is_seg = (int)blockIdx.x >= num_tiles;
   if (is_seg) {
     sidx = blockIdx.x - (uint32_t)num_tiles;
+#if GSR_K7_SEGMAP == 2
+    sidx = gsr_xcd_group_remap(sidx, GSR_K7_SEG_GROUP_LOG2);     // a tile's segments share an XCD (and its L2)
     if (sidx >= seg.seg_total[0]) return;
+#elif GSR_K7_SEGMAP == 1
+    if (sidx >= seg.seg_total[0]) return;
+    sidx = (uint32_t)gsr_xcd_remap((int)sidx, (int)seg.seg_total[0]);
+#else
+    if (sidx >= seg.seg_total[0]) return;
+#endif
     const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
     tile = (int)d[0];
     const uint32_t tstart = tile_range[2 * tile];
@@ -748,7 +762,9 @@ int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const 
   const int tx = (W + 15) / 16, ty = (H + 15) / 16, nt = tx * ty;
   const GsrRasterParams rp = to_params(params_host);
   const SegDev seg = to_segdev(segments_host);
-  const int grid = nt + (segments_host ? (int)segments_host->capacity : 0);
+  // segment blocks: rounded up to the XCD grouping of gsr_xcd_group_remap (blocks past seg_total return)
+  const int seg_round = 8 << GSR_K7_SEG_GROUP_LOG2;
+  const int grid = nt + (segments_host ? (int)((segments_host->capacity + seg_round - 1) / seg_round * seg_round) : 0);
   if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
   else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
   else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);

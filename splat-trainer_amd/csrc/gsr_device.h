@@ -83,3 +83,12 @@ __device__ __forceinline__ int gsr_xcd_remap(int bid, int n) {
   int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + within;
 }
+
+// Grouped variant for work lists whose length is only known on the device: runs of 2^log2_group consecutive items
+// stay on one XCD (they share per-tile data in that XCD's L2) while the runs themselves are dealt round-robin, so every
+// XCD still sees a uniform sample of the image.  Bijective on [0, 8 * 2^log2_group * k); the launch rounds its grid up
+// to that multiple and blocks whose item falls past the end of the list return.
+__device__ __forceinline__ uint32_t gsr_xcd_group_remap(uint32_t bid, uint32_t log2_group) {
+  const uint32_t xcd = bid & 7u, within = bid >> 3;
+  return ((((within >> log2_group) << 3) | xcd) << log2_group) | (within & ((1u << log2_group) - 1u));
+}

@@ -8,7 +8,7 @@ ROUND=${1:-r02}
 WORKLOADS=${2:-"c2 c3"}
 OUT=gpurun_out/prof_${ROUND}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 for W in $WORKLOADS; do
   echo "== $W kernel trace"; 
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${W}_trace" -- python3 bench.py --no-cpu-baseline --workload "$W" > "$OUT/${W}_trace.log" 2>&1

@@ -25,9 +25,14 @@ KERNELS = {"K7": "composite_bwd_kernel", "K6": "composite_fwd_kernel", "K6_segC"
            "tile_sort_scatter": "rs_scatter", "tile_emit": "tile_emit_kernel", "tile_count": "tile_count_kernel"}
 
 
+def newest(pattern):
+  hits = sorted(glob.glob(pattern), key=os.path.getmtime)
+  return hits[-1:] if hits else []
+
+
 def counters(path):
   agg = collections.defaultdict(lambda: collections.defaultdict(list))
-  for f in glob.glob(os.path.join(path, "*", "*counter_collection.csv")):
+  for f in newest(os.path.join(path, "*", "*counter_collection.csv")):      # one run per pass: the most recent
     for r in csv.DictReader(open(f)):
       agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
   return agg
@@ -40,7 +45,7 @@ def main():
                                   capture_output=True, text=True).stdout)
   isa.pop("all_kernels", None)
   for w in workloads:
-    stats = glob.glob(os.path.join(src, f"{w}_trace", "*", "*kernel_stats.csv"))
+    stats = newest(os.path.join(src, f"{w}_trace", "*", "*kernel_stats.csv"))
     if stats:
       shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{rnd}_bench_{w}_kernel_stats.csv"))
     b = os.path.join(src, f"bench_{w}.json")

@@ -69,7 +69,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 15) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 16) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -82,14 +82,16 @@ int gsr_exclusive_scan_u32_checked(const uint32_t* in, uint32_t* out, int64_t n,
                                    uint32_t* overflow_dev, void* workspace, size_t workspace_bytes, void* stream);
 size_t gsr_sort_workspace_bytes(int64_t n);
 /* Stable LSD radix sort of (key, value) pairs by key bits [begin_bit, end_bit); ping-pongs a<->b.
- * Returns 0 if the result ends in (keys_a, vals_a), 1 if in (keys_b, vals_b), negative on error. */
+ * Returns 0 if the result ends in (keys_a, vals_a), 1 if in (keys_b, vals_b), negative on error.
+ * n_dev (may be NULL): device word with the element count when n is only the capacity of the arrays (workspace sized
+ * for n): the sort can then be enqueued before the count has reached the host; min(n, *n_dev) elements are sorted. */
 int gsr_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
                        int vals_are_iota, int begin_bit, int end_bit, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       const uint32_t* n_dev, void* stream);
 /* Same, carrying a second value array with every key (the tile sort moves instance id + depth rank). */
 int gsr_sort_pairs2_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
                         uint32_t* vals2_b, int64_t n, int vals_are_iota, int begin_bit, int end_bit, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        size_t workspace_bytes, const uint32_t* n_dev, void* stream);
 
 /* ---- K1 frustum cull + compaction  (project_to_image, first half) --------------------------------------- */
 size_t gsr_cull_workspace_bytes(int64_t N);
@@ -116,9 +118,12 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
 
 /* ---- K3 spherical-harmonics colour forward / backward  (evaluate_sh_at) --------------------------------- */
 /* sh_features [N,3,K], K in {1,4,9,16}; colour = 0.5 + sum_k sh[c][k] Y_k(normalize(p - camera_pos)). */
-/* jacobian_out [M,9] or NULL: d colour / d position (row-major 3x3 per splat), saved for the backward pass. */
+/* jacobian_out [M,9] or NULL: d colour / d position (row-major 3x3 per splat), saved for the backward pass.
+ * count_dev (may be NULL): device word holding the true row count when M is only an upper bound -- lets the caller
+ * enqueue the colours right behind K1/K2, before the visible count has reached the host (as gsr_project_forward). */
 int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
-                   const float* camera_pos, float* colors_out, float* jacobian_out, void* stream);
+                   const float* camera_pos, float* colors_out, float* jacobian_out, const uint32_t* count_dev,
+                   void* stream);
 /* d_sh_features [N,3,K] and d_positions [N,3] (may be NULL): rows ``indexes`` are written (accumulate = 0, pass
  * zeros) or added to (accumulate = 1).
  * d_positions is the gradient through the view direction normalize(p - camera_pos). */
@@ -157,25 +162,39 @@ int gsr_depth_keys(const float* depth, int64_t M, uint32_t* keys_out, void* stre
 int gsr_tile_count(const float* gaussians2d, const float* depth, const float* features, const uint32_t* order,
                    int64_t M, int32_t C, int32_t W, int32_t H, const GsrRasterParamsC* params_host, float* rec_out,
                    uint32_t* count_out, float* screen_scale_out, void* stream);
-/* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id, inst2rank[...] = k. */
+/* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id, inst2rank[...] = k.
+ * capacity = number of entries the two output arrays hold: instances at or beyond it are dropped, so the call may be
+ * enqueued into buffers sized from a guess while the exact total is still on its way to the host (the caller compares
+ * the total with the capacity afterwards and emits again if it was too small). */
 int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
-                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, void* stream);
+                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, int64_t capacity,
+                  void* stream);
 /* From the tile-sorted keys: per-tile [start, end).  tile_range must be zero-filled by the caller:
  * [num_tiles, 2] uint32. */
-int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range, void* stream);
+int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range,
+                    const uint32_t* O_dev /* NULL, or the device word with the count when O is a capacity */, void* stream);
 
 /* ---- heavy-tile list segmentation ----------------------------------------------------------------------- */
 /* One wave walks one tile's depth-sorted list serially.  A tile with more than seg_pairs pairs is cut into segments of
  * max(seg_pairs, ~len / 32) pairs: its forward walk (still one wave) leaves a checkpoint at every segment end and its
  * backward pass runs one wave per segment; a tile with more than heavy_min (>= seg_pairs) pairs is composited forward by
  * one wave per segment as well.
- * gsr_segment_capacity: host-side bound on the number of segments of a frame with O overlaps (sizes the buffers). */
-int64_t gsr_segment_capacity(int64_t O, int32_t seg_pairs, int32_t heavy_min);
+ *
+ * seg_pairs_cfg / heavy_min_cfg > 0 fix the two thresholds; <= 0 selects them from the frame's pair count O (and
+ * needs_grad): gsr_segment_thresholds returns the values a frame with O pairs is cut with.  The plan kernel evaluates
+ * the same rule, from O or -- O_dev != NULL -- from the device word holding the count, so the plan can be enqueued
+ * before the count has reached the host.
+ * gsr_segment_capacity: host-side bound on the number of segments (sizes the buffers) of a frame with exactly O pairs
+ * (O_is_bound = 0) or with at most O pairs (O_is_bound = 1). */
+int gsr_segment_thresholds(int32_t seg_pairs_cfg, int32_t heavy_min_cfg, int64_t O, int32_t num_tiles, int32_t needs_grad,
+                           int32_t* seg_pairs_out, int32_t* heavy_min_out);
+int64_t gsr_segment_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cfg, int32_t heavy_min_cfg, int32_t num_tiles,
+                             int32_t needs_grad);
 /* tile_seg_out [num_tiles,2], seg_desc_out [capacity,4], seg_total_out [1] (see GsrSegmentsC); seg_total_out must be
  * ZERO on entry (tiles reserve their segment slots with an integer atomic on it). */
-int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs, int32_t heavy_min,
-                     int64_t capacity, uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out,
-                     void* stream);
+int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
+                     int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, uint32_t* tile_seg_out,
+                     uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream);
 
 /* ---- K6 alpha-composite forward ------------------------------------------------------------------------- */
 /* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;
@@ -197,9 +216,10 @@ int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const 
                            void* stream);
 
 /* ---- deterministic per-splat reductions of the per-(tile,splat) partials -------------------------------- */
-/* visibility_out [M] indexed by splat (not rank). */
+/* visibility_out [M] indexed by splat (not rank).  capacity = slots vis_partial holds (the pair count, or the bound
+ * the buffers were sized with: slots at or beyond it are not read). */
 int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
-                          const uint32_t* order, int64_t M, float* visibility_out, void* stream);
+                          const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity, void* stream);
 /* d_gaussians2d [M,6], d_features [M,C], prune_cost [M], split_score [M], indexed by splat. */
 int gsr_reduce_gradients(const float* partial, const float* vis_partial, const uint32_t* offsets,
                          const uint32_t* count, const uint32_t* order, int64_t M, int32_t C, float* d_gaussians2d,

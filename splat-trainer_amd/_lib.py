@@ -8,11 +8,13 @@ import ctypes as C
 import os
 import threading
 
+import torch
+
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class GsrRasterParamsC(C.Structure):
@@ -55,23 +57,24 @@ PROTOTYPES = {
     "gsr_exclusive_scan_u32": (C.c_int, [_p, _p, _i64, _p, _p, _sz, _p]),
     "gsr_exclusive_scan_u32_checked": (C.c_int, [_p, _p, _i64, _p, _p, _p, _sz, _p]),
     "gsr_sort_workspace_bytes": (_sz, [_i64]),
-    "gsr_sort_pairs_u32": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p]),
-    "gsr_sort_pairs2_u32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p]),
+    "gsr_sort_pairs_u32": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p, _p]),
+    "gsr_sort_pairs2_u32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p, _p]),
     "gsr_cull_workspace_bytes": (_sz, [_i64]),
     "gsr_frustum_cull": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _sz, _p]),
     "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p]),
     "gsr_project_backward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _i32, _p]),
-    "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "gsr_sh_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p]),
     "gsr_sh_backward_multi": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p]),
     "gsr_inverse_map": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "gsr_sh_backward_dense": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     "gsr_depth_keys": (C.c_int, [_p, _i64, _p, _p]),
     "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p]),
-    "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),
-    "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p]),
-    "gsr_segment_capacity": (_i64, [_i64, _i32, _i32]),
-    "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i64, _p, _p, _p, _p]),
+    "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p]),
+    "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
+    "gsr_segment_thresholds": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _p, _p]),
+    "gsr_segment_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
+    "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _i64, _p, _p, _p, _p]),
     "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _ps, _p]),
     "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _ps, _p]),
     "gsr_opt_point_weights": (C.c_int, [_p, _p, _i64, _p, _p, _f, _f, _f, _f, _i32, _p, _p]),
@@ -88,12 +91,23 @@ PROTOTYPES = {
     "gsr_compact_offsets": (C.c_int, [_p, _i64, _p, _p, _p, _sz, _p]),
     "gsr_compact_columns": (C.c_int, [_p, _i64, _p, _i64, _i64, C.POINTER(GsrColumnC), _i32, _p]),
     "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p]),
-    "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p]),
+    "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
 }
 
 _lib = None
 _lock = threading.Lock()
+
+
+def current_stream_ptr() -> C.c_void_p:
+  """hipStream_t of torch's current stream on the current device.  (torch.cuda.current_stream() costs ~13 us per call
+  on this stack -- device-availability probing -- and a step makes a dozen launches; the raw getter costs well under 1 us.)"""
+  return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+def current_stream() -> "torch.cuda.Stream":
+  """torch.cuda.current_stream() of the current device without the availability probe (explicit device index)."""
+  return torch.cuda.current_stream(torch._C._cuda_getDevice())
 
 
 class GsplatHipError(RuntimeError):

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict__ rec,
                                                         const uint32_t* __restrict__ offsets, int64_t M, int tiles_x,
                                                         int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ inst2rank) {
+                                                        uint32_t* __restrict__ inst2rank, uint32_t capacity) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   const float4* r = reinterpret_cast<const float4*>(rec + GSR_REC_FLOATS * k);
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict_
   for (int ty = e.y0; ty < e.y1; ++ty)
     for (int tx = e.x0; tx < e.x1; ++tx)
       if (gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty)) {
+        if (o >= capacity) return;            // speculative launch into buffers sized from a guess: the caller re-emits
         keys[o] = (uint32_t)(ty * tiles_x + tx);
         // depth rank in the low 30 bits, which tile halves the support reaches in the top 2
         inst2rank[o] = (uint32_t)k | (gsr_tile_half_mask(u, v, A, B, C, e.qmax, tx, ty) << 30);
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int64_t O,
-                                                          uint32_t* __restrict__ range) {
+                                                          uint32_t* __restrict__ range,
+                                                          const uint32_t* __restrict__ O_dev) {
+  if (O_dev) O = min(O, (int64_t)*O_dev);     // O is a capacity: the pair count is still on the device
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= O) return;
   const uint32_t t = keys[i];
@@ -102,12 +105,14 @@ __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ count,
                                                          const uint32_t* __restrict__ order, int64_t M,
-                                                         float* __restrict__ vis) {
+                                                         float* __restrict__ vis, uint32_t limit) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   const uint32_t b = offsets[k], n = count[k];
   float acc = 0.f;
-  for (uint32_t j = 0; j < n; ++j) acc += vis_partial[b + j];
+  // limit = slots vis_partial holds: a speculative launch (buffers sized from a guess that turned out too small) must
+  // not read past them; its output is discarded by the caller
+  for (uint32_t j = 0; j < n && b + j < limit; ++j) acc += vis_partial[b + j];
   vis[order ? order[k] : (uint32_t)k] = acc;
 }
 
@@ -208,36 +213,40 @@ int gsr_tile_count(const float* gaussians2d, const float* depth, const float* fe
 }
 
 int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
-                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, void* stream_) {
+                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, int64_t capacity,
+                  void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || M >= (1ll << 30) || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (capacity < 0 || capacity > 0x7FFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
   if (!rec || !offsets || !keys_out || !inst2rank_out) return GSR_ERR_INVALID_ARGUMENT;
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
   tile_emit_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rec, offsets, M, tx, ty, to_params(params_host), keys_out,
-                                                        inst2rank_out);
+                                                        inst2rank_out, (uint32_t)capacity);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
 
-int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range, void* stream_) {
+int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range,
+                    const uint32_t* O_dev, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (O < 0 || num_tiles <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (O == 0) return GSR_OK;
   if (!sorted_keys || !tile_range) return GSR_ERR_INVALID_ARGUMENT;
-  tile_ranges_kernel<<<grid_for(O, 256), 256, 0, stream>>>(sorted_keys, O, tile_range);
+  tile_ranges_kernel<<<grid_for(O, 256), 256, 0, stream>>>(sorted_keys, O, tile_range, O_dev);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
 
 int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
-                          const uint32_t* order, int64_t M, float* visibility_out, void* stream_) {
+                          const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M < 0 || capacity < 0 || capacity > 0x7FFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
   if (!offsets || !count || !visibility_out) return GSR_ERR_INVALID_ARGUMENT;
-  reduce_vis_kernel<<<grid_for(M, 256), 256, 0, stream>>>(vis_partial, offsets, count, order, M, visibility_out);
+  reduce_vis_kernel<<<grid_for(M, 256), 256, 0, stream>>>(vis_partial, offsets, count, order, M, visibility_out,
+                                                         (uint32_t)capacity);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -434,7 +434,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
                                                            const int* __restrict__ last,
                                                            const float* __restrict__ dL_dimage,
                                                            const float* __restrict__ image,
-                                                           float* __restrict__ partial, SegDev seg) {
+                                                           float* __restrict__ partial, SegDev seg,
+                                                           uint32_t seg_capacity) {
   // A block walks tile-relative list positions [lo, hi) in reverse: a short tile's whole list, or -- extra blocks of
   // the launch -- one segment of a longer tile, entered with that segment's own end state from the forward pass.
   int tile, lo = 0, seg_hi = 0x7fffffff;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
     sidx = blockIdx.x - (uint32_t)num_tiles;
 #if GSR_K7_SEGMAP == 2
     sidx = gsr_xcd_group_remap(sidx, GSR_K7_SEG_GROUP_LOG2);     // a tile's segments share an XCD (and its L2)
-    if (sidx >= seg.seg_total[0]) return;
+    if (sidx >= min(seg.seg_total[0], seg_capacity)) return;     // (the grid is rounded up past the tables' capacity)
 #elif GSR_K7_SEGMAP == 1
     if (sidx >= seg.seg_total[0]) return;
     sidx = (uint32_t)gsr_xcd_remap((int)sidx, (int)seg.seg_total[0]);
@@ -628,13 +629,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
 // numbered consecutively from a slot range the tile reserves with one integer atomic on the (zero-initialised) segment
 // counter; a tile longer than `heavy_min` is flagged GSR_SEG_HEAVY: its forward pass is segmented too.  Which range a tile gets depends on arrival
 // order; nothing else does: a tile's segments are contiguous and in list order, every result is a function of that alone.
+// (segment length, heavy-tile threshold) of a frame with O (tile, splat) pairs; configuration values <= 0 mean automatic.
+// One definition for the host (buffer sizing, gsr_segment_thresholds) and the plan kernel (which may be launched with O
+// still on the device), so a frame is cut the same way whichever side evaluates it.
+//
+// Heavy threshold: cutting a tile's FORWARD walk only pays when that tile would otherwise outlast the rest of the launch
+// -- a segmented forward pass costs an extra alpha-product pass, so a frame whose tiles are all equally long (3M splats
+// at 1080p: ~800 pairs on EVERY tile) must not be cut there.  A lone wave walks ~6 pairs per microsecond while the
+// balanced launch takes ~(40 + 0.11 O / 1000) us (measured K6 fit): a tile is heavy above about half of what one wave
+// can walk in that time.
+// Segment length: the BACKWARD pass is cheaper to split -- the one-wave forward walk just stores a 4 KB checkpoint per
+// segment end -- and gains from finer work units (measured: K7 -5 % on c2 at 64-pair segments, -13..20 % on c3 at
+// 256..128), so with gradients a tile is cut into about six segments (mean list length / 6 within [64, 256], multiple
+// of 4); without gradients only heavy tiles are cut, into segments half a threshold long.
+__host__ __device__ inline void segment_thresholds(int32_t seg_cfg, int32_t heavy_cfg, int64_t O, int32_t num_tiles,
+                                                   int32_t needs_grad, uint32_t* seg_out, uint32_t* heavy_out) {
+  if (O < 0) O = 0;
+  int64_t heavy = heavy_cfg > 0 ? (int64_t)heavy_cfg : 120 + O / 2900;
+  if (heavy_cfg <= 0 && heavy < 512) heavy = 512;
+  int64_t seg;
+  if (seg_cfg > 0) {
+    seg = seg_cfg;
+  } else {
+    if (needs_grad) {
+      const int64_t per = 6 * (int64_t)(num_tiles > 0 ? num_tiles : 1);
+      seg = (O / per + 3) & ~(int64_t)3;
+      seg = seg < 64 ? 64 : (seg > 256 ? 256 : seg);
+    } else {
+      seg = (heavy / 2) & ~(int64_t)3;
+      if (seg < 256) seg = 256;
+    }
+    seg = (seg + 3) & ~(int64_t)3;
+    if (seg < 4) seg = 4;
+  }
+  *seg_out = (uint32_t)seg;
+  *heavy_out = (uint32_t)(heavy > seg ? heavy : seg);
+}
+
 __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __restrict__ tile_range, int num_tiles,
-                                                           uint32_t seg_pairs, uint32_t heavy_min, uint32_t capacity,
-                                                           uint32_t* __restrict__ tile_seg,
+                                                           int32_t seg_cfg, int32_t heavy_cfg, int32_t needs_grad,
+                                                           int64_t O, const uint32_t* __restrict__ O_dev,
+                                                           uint32_t capacity, uint32_t* __restrict__ tile_seg,
                                                            uint32_t* __restrict__ seg_desc,
                                                            uint32_t* __restrict__ seg_total) {
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (t >= num_tiles) return;
+  uint32_t seg_pairs, heavy_min;
+  segment_thresholds(seg_cfg, heavy_cfg, O_dev ? (int64_t)*O_dev : O, num_tiles, needs_grad, &seg_pairs, &heavy_min);
   const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
   // a heavy tile's segments are also FORWARD work units (alpha-product pass + a prologue over the preceding segments):
   // about 256 pairs each and at most ~128 per tile; a long tile's segments are only checkpoints: seg_pairs each
@@ -684,21 +725,44 @@ inline bool seg_ok(const GsrSegmentsC* sg, bool median) {
 
 extern "C" {
 
-int64_t gsr_segment_capacity(int64_t O, int32_t seg_pairs, int32_t heavy_min) {
-  if (O <= 0 || seg_pairs <= 0 || heavy_min < seg_pairs) return 0;
-  // a tile of len pairs (len > seg_pairs) yields at most ceil(len / seg_pairs) <= len / seg_pairs + 1 segments
-  return O / seg_pairs + O / ((int64_t)seg_pairs + 1) + 1;
+int gsr_segment_thresholds(int32_t seg_pairs_cfg, int32_t heavy_min_cfg, int64_t O, int32_t num_tiles, int32_t needs_grad,
+                           int32_t* seg_pairs_out, int32_t* heavy_min_out) {
+  if (!seg_pairs_out || !heavy_min_out || num_tiles <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  uint32_t seg, heavy;
+  segment_thresholds(seg_pairs_cfg, heavy_min_cfg, O, num_tiles, needs_grad, &seg, &heavy);
+  *seg_pairs_out = (int32_t)seg;
+  *heavy_min_out = (int32_t)heavy;
+  return GSR_OK;
 }
 
-int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs, int32_t heavy_min,
-                     int64_t capacity, uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out,
-                     void* stream_) {
+int64_t gsr_segment_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cfg, int32_t heavy_min_cfg, int32_t num_tiles,
+                             int32_t needs_grad) {
+  if (O <= 0 || num_tiles <= 0) return 0;
+  // a tile of len pairs (len > seg) yields at most ceil(len / seg) <= len / seg + 1 segments, and at most
+  // min(tiles, O / (seg + 1)) tiles are that long
+  if (!O_is_bound || seg_pairs_cfg > 0) {
+    uint32_t seg, heavy;
+    segment_thresholds(seg_pairs_cfg, heavy_min_cfg, O, num_tiles, needs_grad, &seg, &heavy);
+    return O / seg + O / ((int64_t)seg + 1) + 1;
+  }
+  // only a bound on the pair count is known and the segment length follows the true count: for any count <= O the
+  // automatic length is >= 64; while it is below 256 it is >= count / (6 tiles), i.e. <= 6 segments per tile on
+  // average, plus one remainder per tile; at 256 the first formula applies
+  const int64_t by_min = O / 64 + O / 65 + 1;
+  const int64_t T = num_tiles;
+  const int64_t by_rule = (7 * T > O / 256 + T ? 7 * T : O / 256 + T) + 1;
+  return by_min < by_rule ? by_min : by_rule;
+}
+
+int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
+                     int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, uint32_t* tile_seg_out,
+                     uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (num_tiles <= 0 || seg_pairs <= 0 || heavy_min < seg_pairs || capacity <= 0 || capacity > 0x7fffffffll)
-    return GSR_ERR_INVALID_ARGUMENT;
+  if (num_tiles <= 0 || capacity <= 0 || capacity > 0x7fffffffll || (O < 0 && !O_dev)) return GSR_ERR_INVALID_ARGUMENT;
+  if (seg_pairs_cfg > 0 && heavy_min_cfg > 0 && heavy_min_cfg < seg_pairs_cfg) return GSR_ERR_INVALID_ARGUMENT;
   if (!tile_range || !tile_seg_out || !seg_desc_out || !seg_total_out) return GSR_ERR_INVALID_ARGUMENT;
-  segment_plan_kernel<<<(num_tiles + 255) / 256, 256, 0, stream>>>(tile_range, num_tiles, (uint32_t)seg_pairs,
-                                                                  (uint32_t)heavy_min, (uint32_t)capacity, tile_seg_out,
+  segment_plan_kernel<<<(num_tiles + 255) / 256, 256, 0, stream>>>(tile_range, num_tiles, seg_pairs_cfg, heavy_min_cfg,
+                                                                  needs_grad, O, O_dev, (uint32_t)capacity, tile_seg_out,
                                                                   seg_desc_out, seg_total_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
@@ -765,9 +829,9 @@ int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const 
   // segment blocks: rounded up to the XCD grouping of gsr_xcd_group_remap (blocks past seg_total return)
   const int seg_round = 8 << GSR_K7_SEG_GROUP_LOG2;
   const int grid = nt + (segments_host ? (int)((segments_host->capacity + seg_round - 1) / seg_round * seg_round) : 0);
-  if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
-  else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
-  else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg);
+  if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, (uint32_t)(segments_host ? segments_host->capacity : 0));
+  else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, (uint32_t)(segments_host ? segments_host->capacity : 0));
+  else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, (uint32_t)(segments_host ? segments_host->capacity : 0));
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -119,9 +119,10 @@ template <int K, bool JAC>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ sh, const float* __restrict__ pos,
                                                      const int64_t* __restrict__ idx, int64_t M,
                                                      const float* __restrict__ cam_pos, float* __restrict__ out,
-                                                     float* __restrict__ jac) {
+                                                     float* __restrict__ jac, const uint32_t* __restrict__ count_dev) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+  // M is an upper bound when count_dev is given (the visible count is still on the device, as in project_fwd_kernel)
+  if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
   const int64_t i = idx[m];
   float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
   const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -377,7 +378,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 15; }
+int gsr_abi_version(void) { return 16; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -464,7 +465,8 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
 }
 
 int gsr_sh_forward(const float* sh_features, const float* positions, const int64_t* indexes, int64_t M, int32_t K,
-                   const float* camera_pos, float* colors_out, float* jacobian_out, void* stream_) {
+                   const float* camera_pos, float* colors_out, float* jacobian_out, const uint32_t* count_dev,
+                   void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
@@ -473,20 +475,20 @@ int gsr_sh_forward(const float* sh_features, const float* positions, const int64
   const unsigned g = grid_for(M, 256);
   switch (K) {
     case 1:
-      if (jacobian_out) sh_fwd_kernel<1, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
-      else sh_fwd_kernel<1, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      if (jacobian_out) sh_fwd_kernel<1, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out, count_dev);
+      else sh_fwd_kernel<1, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr, count_dev);
       break;
     case 4:
-      if (jacobian_out) sh_fwd_kernel<4, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
-      else sh_fwd_kernel<4, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      if (jacobian_out) sh_fwd_kernel<4, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out, count_dev);
+      else sh_fwd_kernel<4, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr, count_dev);
       break;
     case 9:
-      if (jacobian_out) sh_fwd_kernel<9, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
-      else sh_fwd_kernel<9, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      if (jacobian_out) sh_fwd_kernel<9, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out, count_dev);
+      else sh_fwd_kernel<9, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr, count_dev);
       break;
     default:
-      if (jacobian_out) sh_fwd_kernel<16, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out);
-      else sh_fwd_kernel<16, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr);
+      if (jacobian_out) sh_fwd_kernel<16, true><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, jacobian_out, count_dev);
+      else sh_fwd_kernel<16, false><<<g, 256, 0, stream>>>(sh_features, positions, indexes, M, camera_pos, colors_out, nullptr, count_dev);
       break;
   }
   GSR_CHECK_LAUNCH();

@@ -143,8 +143,9 @@ inline int rs_rounds_for(int64_t n) { return n < (4ll << 20) ? 4 : 16; }     // 
 
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
                                                              uint32_t mask, int rounds, uint32_t* __restrict__ hist,
-                                                             uint32_t num_blocks) {
+                                                             uint32_t num_blocks, const uint32_t* __restrict__ n_dev) {
   __shared__ uint32_t s_hist[RS_BINS];
+  if (n_dev) n = min(n, *n_dev);              // n is a capacity: the element count is still on the device
   s_hist[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * (uint32_t)(rounds * RS_THREADS);
@@ -218,8 +219,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
                                                                 uint32_t* __restrict__ vals2_out, uint32_t n, int shift,
                                                                 uint32_t mask, const uint32_t* __restrict__ counts,
                                                                 const uint32_t* __restrict__ offsets,
-                                                                uint32_t num_blocks) {
+                                                                uint32_t num_blocks, const uint32_t* __restrict__ n_dev) {
   constexpr int TILE = ROUNDS * RS_THREADS;
+  if (n_dev) n = min(n, *n_dev);
+  if (blockIdx.x * (uint32_t)TILE >= n) return;   // uniform over the block; its histogram row is all zeros
   __shared__ uint32_t s_start[RS_BINS];       // first image slot of each digit
   __shared__ uint32_t s_goff[RS_BINS];        // global slot of the digit's first element of this block
   __shared__ uint32_t s_run[RS_BINS];         // elements of the digit placed by earlier rounds
@@ -301,7 +304,7 @@ size_t sort_ws_bytes(int64_t n) {
 
 int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
               uint32_t* vals2_b, int64_t n, int vals_are_iota, int begin_bit, int end_bit, void* workspace,
-              size_t workspace_bytes, hipStream_t stream) {
+              size_t workspace_bytes, const uint32_t* n_dev, hipStream_t stream) {
   const bool two = vals2_a != nullptr;
   if (n < 0 || n > 0x7FFFFFFFll || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return GSR_ERR_INVALID_ARGUMENT;
   if (n > 0 && (!keys_a || !vals_a || !keys_b || !vals_b || (two && !vals2_b))) return GSR_ERR_INVALID_ARGUMENT;
@@ -327,7 +330,7 @@ int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* k
     int bits = end_bit - bit; if (bits > 8) bits = 8; if (bits < 0) bits = 0;
     const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
     uint32_t* tot = totals + (size_t)p * RS_BINS;
-    rs_hist_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, rounds, hist, nb);
+    rs_hist_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, rounds, hist, nb, n_dev);
     GSR_CHECK_LAUNCH();
     rs_row_total_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
     GSR_CHECK_LAUNCH();
@@ -335,7 +338,7 @@ int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* k
     GSR_CHECK_LAUNCH();
 #define GSR_RS_SCATTER(TWO_, R_)                                                                                     \
   rs_scatter_kernel<TWO_, R_><<<nb, RS_THREADS, 0, stream>>>(kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, \
-                                                             hist, offs, nb)
+                                                             hist, offs, nb, n_dev)
     if (two) { if (rounds == 4) GSR_RS_SCATTER(true, 4); else GSR_RS_SCATTER(true, 16); }
     else     { if (rounds == 4) GSR_RS_SCATTER(false, 4); else GSR_RS_SCATTER(false, 16); }
 #undef GSR_RS_SCATTER
@@ -378,18 +381,18 @@ size_t gsr_sort_workspace_bytes(int64_t n) { return sort_ws_bytes(n); }
 // is in the *_a buffers and 1 when it is in the *_b buffers, or a negative error code.
 int gsr_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
                        int vals_are_iota, int begin_bit, int end_bit, void* workspace, size_t workspace_bytes,
-                       void* stream_) {
+                       const uint32_t* n_dev, void* stream_) {
   return sort_impl(keys_a, vals_a, nullptr, keys_b, vals_b, nullptr, n, vals_are_iota, begin_bit, end_bit, workspace,
-                   workspace_bytes, reinterpret_cast<hipStream_t>(stream_));
+                   workspace_bytes, n_dev, reinterpret_cast<hipStream_t>(stream_));
 }
 
 // Same, carrying a second value array (vals2) along with every key.
 int gsr_sort_pairs2_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
                         uint32_t* vals2_b, int64_t n, int vals_are_iota, int begin_bit, int end_bit, void* workspace,
-                        size_t workspace_bytes, void* stream_) {
+                        size_t workspace_bytes, const uint32_t* n_dev, void* stream_) {
   if (n > 0 && !vals2_a) return GSR_ERR_INVALID_ARGUMENT;
   return sort_impl(keys_a, vals_a, vals2_a, keys_b, vals_b, vals2_b, n, vals_are_iota, begin_bit, end_bit, workspace,
-                   workspace_bytes, reinterpret_cast<hipStream_t>(stream_));
+                   workspace_bytes, n_dev, reinterpret_cast<hipStream_t>(stream_));
 }
 
 }  // extern "C"

@@ -19,8 +19,7 @@ import torch
 from . import _lib
 
 
-def _stream():
-  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _lib.current_stream_ptr
 
 
 def _p(t: Optional[torch.Tensor]):

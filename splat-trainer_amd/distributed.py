@@ -126,7 +126,7 @@ def exchange_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank
   ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
   _lib.check(lib.gsr_sh_backward_multi(C.c_void_p(base), stride, C.c_void_p(base + 4 * 3 * N), stride, block.shape[0],
                                        ptr(sh_features.detach()), ptr(positions.detach()), N, K, ptr(d_sh), ptr(d_pos),
-                                       int(accumulate), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                       int(accumulate), _lib.current_stream_ptr()),
              "gsr_sh_backward_multi")
   collector.clear()
 

@@ -21,8 +21,7 @@ def _ptr(t):
   return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _lib.current_stream_ptr
 
 
 def _strides(t: torch.Tensor):

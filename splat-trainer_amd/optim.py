@@ -155,7 +155,7 @@ class ParameterClass:
     vis = visibility.to(torch.float32).contiguous() if (opt.visibility_aware and visibility is not None) else None
     if vis is not None and vis.shape[0] != M:
       raise ValueError("visibility and indexes differ in length")
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    stream = _lib.current_stream_ptr()
     row_scale = torch.empty(M, 4, dtype=torch.float32, device=indexes.device)
     st = self._state
     _lib.check(lib.gsr_opt_point_weights(_ptr(indexes), _ptr(vis), M, _ptr(st["step"]), _ptr(st["vis_avg"]),

@@ -19,12 +19,14 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import Optional, Tuple
 
 import torch
 
 from . import _lib
 from .data_types import CameraParams, Gaussians3D, RasterConfig, RenderedPoints, Rendering
+from . import sh as _sh
 from .sh import evaluate_sh_at
 
 REC_FLOATS = 12
@@ -45,12 +47,12 @@ class KernelTimer:
     a few hundred microseconds that would otherwise land inside somebody's timed step)."""
     for _ in range(n):
       e = torch.cuda.Event(enable_timing=True)
-      e.record(torch.cuda.current_stream())
+      e.record(_lib.current_stream())
       self._pool.append(e)
 
   def _event(self):
     e = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
-    e.record(torch.cuda.current_stream())
+    e.record(_lib.current_stream())
     return e
 
   def begin(self, name: str):
@@ -78,8 +80,7 @@ def _ptr(t: Optional[torch.Tensor]):
   return C.c_void_p(t.data_ptr())
 
 
-def _stream():
-  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _lib.current_stream_ptr
 
 
 def _require_device(*tensors: torch.Tensor):
@@ -116,6 +117,30 @@ def frustum_cull(position: torch.Tensor, camera_params: CameraParams, config: Ra
                                   _ptr(ws), ws_bytes, _stream()), "gsr_frustum_cull")
   M = int(count.item())          # host sync #1: the index tensor's size is data dependent
   return indexes[:M]
+
+
+# ------------------------------------------------------------------------------- data-dependent sizes
+_TLS = threading.local()
+
+
+def _start_readback(words: torch.Tensor):
+  """Begins the device->host copy of a few int32 words on the current stream and returns ``wait() -> list``.
+  The two sizes the path cannot know in advance (visible splats, tile overlaps) come back this way: whatever is
+  enqueued between this call and ``wait()`` runs while the host blocks on the COPY's event, not on the stream, so the
+  GPU does not idle through the host's round trip.  One pinned landing buffer + event per thread and device."""
+  pool = _TLS.__dict__.setdefault("readback", {})
+  key = words.device.index
+  if key not in pool:
+    pool[key] = (torch.empty(8, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+  host, event = pool[key]
+  n = words.numel()
+  host[:n].copy_(words, non_blocking=True)
+  event.record(_lib.current_stream())
+
+  def wait():
+    event.synchronize()
+    return host[:n].tolist()
+  return wait
 
 
 class GradOut:
@@ -166,7 +191,15 @@ class _ProjectFn(torch.autograd.Function):
     _lib.check(lib.gsr_project_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes_full), N, _ptr(T),
                                        _ptr(proj), C.byref(params), _ptr(g2d_full), _ptr(depth_full), _ptr(count),
                                        stream), "gsr_project_forward")
-    M = int(count.item())          # host sync #1 (K2 is already running)
+    wait = _start_readback(count)  # host sync #1 (K2 is already running)
+    sh_job = prefetch.pop("sh", None) if prefetch is not None else None
+    if sh_job is not None and N > 0:
+      # the colours only need `indexes`: K3 goes in behind K2 with the count still on the device and keeps the GPU
+      # busy for the ~40 us the host needs to read M back and get to its next launch
+      sh_out = _sh.launch_forward_counted(*sh_job[:3], indexes_full, count, sh_job[3])
+    M = int(wait()[0])
+    if sh_job is not None and N > 0:
+      prefetch["sh_out"] = (sh_out[0][:M], sh_out[1][:M] if sh_out[1] is not None else None)
     indexes, g2d, depth = indexes_full[:M], g2d_full[:M], depth_full[:M]
     if prefetch is not None and M > 0:
       # the caller will rasterize next: the depth sort needs only `depth`, so it is enqueued now and runs while the host
@@ -251,52 +284,39 @@ def _launch_depth_order(depth: torch.Tensor, M: int) -> torch.Tensor:
   sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
   _lib.check(lib.gsr_depth_keys(_ptr(depth), M, _ptr(keys_a), stream), "gsr_depth_keys")
   where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, 32,
-                                            _ptr(sort_ws), sort_bytes, stream), "gsr_sort_pairs_u32(depth)")
+                                            _ptr(sort_ws), sort_bytes, None, stream), "gsr_sort_pairs_u32(depth)")
   return vals_b if where == 1 else vals_a
 
 
 def _segment_thresholds(seg_pairs: int, seg_min: int, O: int, num_tiles: int, needs_grad: bool):
-  """(segment length, heavy-tile threshold) of a frame; explicit config values win, negative / zero mean automatic.
-
-  Heavy threshold: cutting a tile's FORWARD walk only pays when that tile would otherwise outlast the rest of the
-  launch -- a segmented forward pass costs an extra alpha-product pass, so a frame whose tiles are all equally long
-  (3M splats at 1080p: ~800 pairs on EVERY tile) must not be cut there.  A lone wave walks ~6 pairs per microsecond
-  while the balanced launch takes ~(40 + 0.11 O / 1000) us (measured K6 fit), so a tile is heavy above about half of
-  what one wave can walk in that time.
-
-  Segment length: the BACKWARD pass is cheaper to split -- the one-wave forward walk just stores a 4 KB checkpoint per
-  segment end (+10 % on K6 at three checkpoints per tile) -- and gains from finer work units (measured: K7 -5 % on c2 at
-  64-pair segments with K6 paying as much; K7 -13 % at 256-pair and -20 % at 128-pair segments on c3 for +2..4 % on K6),
-  so with gradients on a tile is cut into about six segments (mean list length / 6, within [64, 256], multiple of 4);
-  without gradients only heavy tiles are cut, into segments half a threshold long."""
-  heavy = seg_min if seg_min > 0 else max(512, 120 + O // 2900)
-  if seg_pairs > 0:
-    seg = seg_pairs
-  elif needs_grad:
-    seg = min(256, max(64, (O // max(6 * num_tiles, 1) + 3) & ~3))
-  else:
-    seg = max(256, (heavy // 2) & ~3)
-  seg = max(4, (seg + 3) & ~3) if seg_pairs <= 0 else seg
-  return seg, max(heavy, seg)
+  """(segment length, heavy-tile threshold) a frame with O pairs is cut with; explicit config values win, negative /
+  zero mean automatic.  The rule lives in the library (composite.hip: segment_thresholds), where the plan kernel
+  evaluates it too -- possibly from a pair count that is still on the device."""
+  seg, heavy = C.c_int32(0), C.c_int32(0)
+  _lib.check(_lib.load().gsr_segment_thresholds(int(seg_pairs), int(seg_min), int(O), int(num_tiles), int(bool(needs_grad)),
+                                                C.byref(seg), C.byref(heavy)), "gsr_segment_thresholds")
+  return seg.value, heavy.value
 
 
-def _plan_segments(st: "_RasterState", num_tiles: int, O: int, dev, stream, seg_total: torch.Tensor):
-  """Heavy-tile list segmentation (composite.hip): tiles with more than ``segment_min_pairs`` pairs are cut into
-  segments of at most ``segment_pairs``; returns the GsrSegmentsC the composite calls take, or None when switched off.
-  The tables are sized from a host-side bound on the segment count, so no extra sync is needed.  ``seg_total``: a
-  zero-initialised device word (the plan kernel's tiles reserve their segment slots on it)."""
+def _plan_segments(st: "_RasterState", num_tiles: int, pairs: int, pairs_dev: Optional[torch.Tensor], dev, stream,
+                   seg_total: torch.Tensor):
+  """List segmentation (composite.hip): tiles longer than the frame's segment length are cut into segments; returns the
+  GsrSegmentsC the composite calls take, or None when switched off.  ``pairs`` is the frame's pair count, or -- with
+  ``pairs_dev``, the device word holding the count -- only an upper bound on it: the tables are then sized for any
+  count up to the bound and the plan kernel reads the count itself.  ``seg_total``: a zero-initialised device word (the
+  plan kernel's tiles reserve their segment slots on it)."""
   st.segment_buffers = None
   if st.seg_pairs == 0:
     return None
   lib = _lib.load()
-  seg_pairs, seg_min = _segment_thresholds(st.seg_pairs, st.seg_min, O, num_tiles, st.needs_grad)
-  cap = int(lib.gsr_segment_capacity(O, seg_pairs, seg_min))
+  grads = int(bool(st.needs_grad))
+  cap = int(lib.gsr_segment_capacity(pairs, 0 if pairs_dev is None else 1, st.seg_pairs, st.seg_min, num_tiles, grads))
   if cap <= 0:
     return None
   tables = torch.empty(2 * num_tiles + 4 * cap, dtype=torch.int32, device=dev)
   tile_seg, seg_desc = tables[:2 * num_tiles], tables[2 * num_tiles:]
-  _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, seg_pairs, seg_min, cap, _ptr(tile_seg),
-                                  _ptr(seg_desc), _ptr(seg_total), stream), "gsr_segment_plan")
+  _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, st.seg_pairs, st.seg_min, grads, pairs, _ptr(pairs_dev),
+                                  cap, _ptr(tile_seg), _ptr(seg_desc), _ptr(seg_total), stream), "gsr_segment_plan")
   planes = 5 + (1 if st.want_median else 0)                       # (T, c0, c1, c2) interleaved + alpha products (+ median)
   pix = torch.empty(planes * cap * 256, dtype=torch.float32, device=dev)
   seg_last = torch.empty(cap * 256, dtype=torch.int32, device=dev)
@@ -353,58 +373,76 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   scan_ws = torch.empty(scan_bytes, dtype=torch.uint8, device=dev)
   _lib.check(lib.gsr_exclusive_scan_u32_checked(_ptr(st.count), _ptr(st.offsets), M, _ptr(total), _ptr(total[1:]),
                                                 _ptr(scan_ws), scan_bytes, stream), "gsr_exclusive_scan_u32_checked")
-  O, overflow = total.tolist()   # host sync #2: number of (tile, splat) overlaps sizes the sort buffers
+  wait = _start_readback(total)  # host "sync" #2: the number of (tile, splat) overlaps
+
+  def rasterize(capacity: int, pairs_dev: Optional[torch.Tensor]):
+    """K4 emit -> K5 tile sort -> tile ranges -> segment plan -> K6 (+ per-splat visibility) into buffers holding
+    ``capacity`` pairs.  With ``pairs_dev`` (the device word with the pair count) the capacity is only a bound: every
+    kernel that needs the count reads it there, so the whole chain is enqueued before the count has reached the host."""
+    tkeys_a, trank_a = _u32(capacity, dev), _u32(capacity, dev)
+    _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
+                                 _ptr(trank_a), capacity, stream), "gsr_tile_emit")
+    tkeys_b, tvals_a, tvals_b, trank_b = _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev)
+    # everything that must start at zero comes out of ONE zero-filled allocation (one fill launch instead of three)
+    n_vis = capacity if need_vis_partial else 0
+    zeros = torch.zeros(2 * M + 2 * num_tiles + 1 + n_vis, dtype=torch.float32, device=dev)
+    heuristics(zeros[:2 * M].view(2, M))
+    # K6 writes every pixel of every tile (an empty tile writes colour 0, T 1, last 0): no zero-fills needed
+    image = torch.empty(H, W, C_, dtype=torch.float32, device=dev)
+    st.final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
+    st.last = torch.empty(H, W, dtype=torch.int32, device=dev)
+    st.median = torch.empty(H, W, dtype=torch.float32, device=dev) if st.want_median else None
+    st.visibility = (torch.empty if st.compute_visibility else torch.zeros)(M, dtype=torch.float32, device=dev)
+
+    # stable-sort the pairs by tile id, find per-tile ranges
+    tile_bits = max(1, int(math.ceil(math.log2(num_tiles)))) if num_tiles > 1 else 1
+    tsort_bytes = lib.gsr_sort_workspace_bytes(capacity)
+    tsort_ws = torch.empty(tsort_bytes, dtype=torch.uint8, device=dev)
+    # values: instance id (implicit 0..O-1) and depth rank travel with the tile key
+    where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(tkeys_a), _ptr(tvals_a), _ptr(trank_a), _ptr(tkeys_b), _ptr(tvals_b),
+                                               _ptr(trank_b), capacity, 1, 0, tile_bits, _ptr(tsort_ws), tsort_bytes,
+                                               _ptr(pairs_dev), stream), "gsr_sort_pairs2_u32(tile)")
+    sorted_keys, st.sorted_inst, st.sorted_rank = (tkeys_b, tvals_b, trank_b) if where == 1 else (tkeys_a, tvals_a, trank_a)
+    st.tile_range = zeros[2 * M:2 * M + 2 * num_tiles].view(torch.int32).view(num_tiles, 2)
+    _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), capacity, num_tiles, _ptr(st.tile_range), _ptr(pairs_dev), stream),
+               "gsr_tile_ranges")
+
+    st.vis_partial = zeros[2 * M + 2 * num_tiles + 1:] if need_vis_partial else None
+    st.pair_vis = torch.empty(capacity, dtype=torch.float32, device=dev) if need_vis_partial else None
+    st.segments = _plan_segments(st, num_tiles, capacity, pairs_dev, dev, stream,
+                                 zeros[2 * M + 2 * num_tiles:2 * M + 2 * num_tiles + 1].view(torch.int32))
+    timer = KERNEL_TIMER
+    if timer is not None:
+      timer.begin("composite_forward")
+    _lib.check(lib.gsr_composite_forward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
+                                         _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
+                                         _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
+                                         _ptr(st.pair_vis), _seg_ref(st), stream), "gsr_composite_forward")
+    if timer is not None:
+      timer.end("composite_forward")
+    if st.compute_visibility:
+      _lib.check(lib.gsr_reduce_visibility(_ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count), _ptr(st.order),
+                                           M, _ptr(st.visibility), capacity, stream), "gsr_reduce_visibility")
+    return image
+
+  # The O-sized buffers are sized from the totals of the frames before and the whole chain is enqueued BEFORE this frame's
+  # total is known: the GPU never waits for the host's round trip, and by the time the host looks at the total (after
+  # the composite launch) it has long arrived.  Only a frame that outgrows the guess is run again, with exact sizes.
+  # Nothing in the result depends on the guess: kernels take the pair count from the device and ignore the slack.
+  guesses = _TLS.__dict__.setdefault("overlap_guess", {})
+  guess = guesses.get(dev.index, 0)
+  image = rasterize(guess, total[:1]) if guess > 0 else None
+  O, overflow = wait()
   if overflow or O < 0:          # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
     raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
   st.O = O
+  guesses[dev.index] = min(max(O + O // 4 + 4096, guess - guess // 64), 0x7fffffff)   # grows at once, decays slowly
   if O == 0:
+    st.segments, st.segment_buffers = None, None
     heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))
     return blank()
-  # emit (tile id, instance) in depth order first: its two output arrays are all it needs, and the GPU has been idle
-  # since the sync -- every other O-sized allocation happens while it runs
-  tkeys_a, trank_a = _u32(O, dev), _u32(O, dev)
-  _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
-                               _ptr(trank_a), stream), "gsr_tile_emit")
-  tkeys_b, tvals_a, tvals_b, trank_b = _u32(O, dev), _u32(O, dev), _u32(O, dev), _u32(O, dev)
-  # everything that must start at zero comes out of ONE zero-filled allocation (one fill launch instead of three)
-  n_vis = O if need_vis_partial else 0
-  zeros = torch.zeros(2 * M + 2 * num_tiles + 1 + n_vis, dtype=torch.float32, device=dev)
-  heuristics(zeros[:2 * M].view(2, M))
-  # K6 writes every pixel of every tile (an empty tile writes colour 0, T 1, last 0): no zero-fills needed
-  image = torch.empty(H, W, C_, dtype=torch.float32, device=dev)
-  st.final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
-  st.last = torch.empty(H, W, dtype=torch.int32, device=dev)
-  st.median = torch.empty(H, W, dtype=torch.float32, device=dev) if st.want_median else None
-  st.visibility = (torch.empty if st.compute_visibility else torch.zeros)(M, dtype=torch.float32, device=dev)
-
-  # stable-sort the pairs by tile id, find per-tile ranges
-  tile_bits = max(1, int(math.ceil(math.log2(num_tiles)))) if num_tiles > 1 else 1
-  tsort_bytes = lib.gsr_sort_workspace_bytes(O)
-  tsort_ws = torch.empty(tsort_bytes, dtype=torch.uint8, device=dev)
-  # values: instance id (implicit 0..O-1) and depth rank travel with the tile key
-  where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(tkeys_a), _ptr(tvals_a), _ptr(trank_a), _ptr(tkeys_b), _ptr(tvals_b),
-                                             _ptr(trank_b), O, 1, 0, tile_bits, _ptr(tsort_ws), tsort_bytes, stream),
-                     "gsr_sort_pairs2_u32(tile)")
-  sorted_keys, st.sorted_inst, st.sorted_rank = (tkeys_b, tvals_b, trank_b) if where == 1 else (tkeys_a, tvals_a, trank_a)
-  st.tile_range = zeros[2 * M:2 * M + 2 * num_tiles].view(torch.int32).view(num_tiles, 2)
-  _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), O, num_tiles, _ptr(st.tile_range), stream), "gsr_tile_ranges")
-
-  st.vis_partial = zeros[2 * M + 2 * num_tiles + 1:] if need_vis_partial else None
-  st.pair_vis = torch.empty(O, dtype=torch.float32, device=dev) if need_vis_partial else None
-  st.segments = _plan_segments(st, num_tiles, O, dev, stream,
-                               zeros[2 * M + 2 * num_tiles:2 * M + 2 * num_tiles + 1].view(torch.int32))
-  timer = KERNEL_TIMER
-  if timer is not None:
-    timer.begin("composite_forward")
-  _lib.check(lib.gsr_composite_forward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
-                                       _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
-                                       _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
-                                       _ptr(st.pair_vis), _seg_ref(st), stream), "gsr_composite_forward")
-  if timer is not None:
-    timer.end("composite_forward")
-  if st.compute_visibility:
-    _lib.check(lib.gsr_reduce_visibility(_ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count), _ptr(st.order),
-                                         M, _ptr(st.visibility), stream), "gsr_reduce_visibility")
+  if image is None or O > guess:
+    image = rasterize(O, None)
   return image
 
 
@@ -495,15 +533,21 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
   otherwise it is an (N, C) per-point colour."""
   config = config or RasterConfig()
   prefetch = {}
-  g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out, prefetch=prefetch)
+  sh_out = None
   if use_sh:
-    sh_out = None
     if sh_collector is not None:            # data-parallel: exchange colour-gradient factors, not d_sh (sh.py)
       sh_out = sh_collector
     elif grad_out is not None:
       sh_out = (grad_out._check("feature", gaussians.feature), grad_out._check("position", gaussians.position), grad_out)
-    feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_params.camera_position,
-                           grad_out=sh_out)
+    camera_pos = camera_params.camera_position
+    if gaussians.feature.is_cuda and gaussians.feature.dim() == 3 and gaussians.feature.shape[2] in (1, 4, 9, 16):
+      # K3 rides behind K1 + K2 inside project_to_image, before the visible count has reached the host
+      prefetch["sh"] = (gaussians.feature, gaussians.position, camera_pos,
+                        _sh.wants_position_grad(gaussians.position, sh_out))
+  g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out, prefetch=prefetch)
+  if use_sh:
+    feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_pos, grad_out=sh_out,
+                           _precomputed=prefetch.pop("sh_out", None))
   else:
     if grad_out is not None:
       raise ValueError("grad_out with use_sh=False: gather the features yourself or use plain autograd")

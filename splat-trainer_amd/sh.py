@@ -18,8 +18,7 @@ def _ptr(t):
   return C.c_void_p(t.data_ptr())
 
 
-def _stream():
-  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = _lib.current_stream_ptr
 
 
 class ShFactorCollector:
@@ -35,21 +34,47 @@ class ShFactorCollector:
     self.items.clear()
 
 
+def as_kernel_inputs(sh_features, positions, camera_pos):
+  """The float32 contiguous views the kernels read (no copies when the caller already holds such tensors)."""
+  return (sh_features.detach().to(torch.float32).contiguous(), positions.detach().to(torch.float32).contiguous(),
+          camera_pos.detach().to(torch.float32).contiguous())
+
+
+def wants_position_grad(positions, grad_out) -> bool:
+  return torch.is_grad_enabled() and not isinstance(grad_out, ShFactorCollector) and \
+      (positions.requires_grad or (grad_out is not None and grad_out[1] is not None))
+
+
+def launch_forward_counted(sh_features, positions, camera_pos, indexes_full, count_dev, want_pos_grad: bool):
+  """K3 over an index buffer whose fill count is still on the device: N-sized outputs, rows past the count are left
+  unwritten.  render_gaussians enqueues this right behind K1 + K2 so the GPU has work while the host reads the count
+  back; the (out, jac) pair it returns is narrowed to M rows and handed to evaluate_sh_at(_precomputed=...)."""
+  lib = _lib.load()
+  sh, pos, cam = as_kernel_inputs(sh_features, positions, camera_pos)
+  N, K = indexes_full.shape[0], sh.shape[2]
+  out = torch.empty(N, 3, dtype=torch.float32, device=sh.device)
+  jac = torch.empty(N, 9, dtype=torch.float32, device=sh.device) if (want_pos_grad and K > 1 and N > 0) else None
+  _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(indexes_full), N, K, _ptr(cam), _ptr(out), _ptr(jac),
+                                _ptr(count_dev), _stream()), "gsr_sh_forward")
+  return out, jac
+
+
 class _SHFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad):
+  def forward(ctx, sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad, precomputed):
     lib = _lib.load()
-    sh = sh_features.detach().to(torch.float32).contiguous()
-    pos = positions.detach().to(torch.float32).contiguous()
-    cam = camera_pos.detach().to(torch.float32).contiguous()
+    sh, pos, cam = as_kernel_inputs(sh_features, positions, camera_pos)
     idx = indexes.contiguous()
     M, K = idx.shape[0], sh.shape[2]
-    out = torch.empty(M, 3, dtype=torch.float32, device=sh.device)
-    # d colour / d position is cheap to form while the coefficient row is in registers; saving it (36 B per
-    # splat) spares the backward pass a second sweep over the 12K-byte rows
-    jac = torch.empty(M, 9, dtype=torch.float32, device=sh.device) if (want_pos_grad and K > 1 and M > 0) else None
-    _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(out), _ptr(jac), _stream()),
-               "gsr_sh_forward")
+    if precomputed is not None:
+      out, jac = precomputed     # launch_forward_counted ran behind the projection, before M was known on the host
+    else:
+      out = torch.empty(M, 3, dtype=torch.float32, device=sh.device)
+      # d colour / d position is cheap to form while the coefficient row is in registers; saving it (36 B per
+      # splat) spares the backward pass a second sweep over the 12K-byte rows
+      jac = torch.empty(M, 9, dtype=torch.float32, device=sh.device) if (want_pos_grad and K > 1 and M > 0) else None
+      _lib.check(lib.gsr_sh_forward(_ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(out), _ptr(jac), None,
+                                    _stream()), "gsr_sh_forward")
     ctx.save_for_backward(sh, pos, idx, cam)
     ctx.jac = jac
     ctx.grad_out = grad_out
@@ -65,7 +90,7 @@ class _SHFn(torch.autograd.Function):
     go = ctx.grad_out
     if isinstance(go, ShFactorCollector):    # data-parallel factor exchange: keep only the colour gradient
       go.items.append((idx, d_out.detach().to(torch.float32).contiguous(), cam))
-      return None, None, None, None, None, None
+      return None, None, None, None, None, None, None
     g = d_out.detach().to(torch.float32).contiguous() if M > 0 else None
     owner = go[2] if (go is not None and len(go) > 2) else None
     overwrite = go is None or (owner is not None and owner.feature_uninitialized)
@@ -91,13 +116,13 @@ class _SHFn(torch.autograd.Function):
     if owner is not None:
       owner.feature_uninitialized = False
     if go is not None:
-      return None, None, None, None, None, None
+      return None, None, None, None, None, None, None
     return (d_sh.to(ctx.in_dtypes[0]), d_pos.to(ctx.in_dtypes[1]) if d_pos is not None else None,
-            None, None, None, None)
+            None, None, None, None, None)
 
 
 def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: torch.Tensor,
-                   camera_pos: torch.Tensor, grad_out=None) -> torch.Tensor:
+                   camera_pos: torch.Tensor, grad_out=None, _precomputed=None) -> torch.Tensor:
   """``sh_features (N,3,K)``, ``positions (N,3)``, ``indexes (M,) int64``, ``camera_pos (3,)`` -> ``(M,3)``.
 
   colour_c = 0.5 + sum_k sh[idx, c, k] * Y_k(normalize(positions[idx] - camera_pos)), K in {1,4,9,16}
@@ -112,6 +137,5 @@ def evaluate_sh_at(sh_features: torch.Tensor, positions: torch.Tensor, indexes: 
     raise ValueError(f"sh_features must be (N,3,K) with K in (1,4,9,16), got {tuple(sh_features.shape)}")
   if indexes.dtype != torch.int64:
     raise TypeError("indexes must be int64")
-  want_pos_grad = torch.is_grad_enabled() and not isinstance(grad_out, ShFactorCollector) and \
-      (positions.requires_grad or (grad_out is not None and grad_out[1] is not None))
-  return _SHFn.apply(sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad)
+  want_pos_grad = wants_position_grad(positions, grad_out)
+  return _SHFn.apply(sh_features, positions, indexes, camera_pos, grad_out, want_pos_grad, _precomputed)

@@ -45,12 +45,12 @@ def _sort(keys: np.ndarray, begin_bit: int, end_bit: int, iota=True, vals=None):
   nbytes = lib.gsr_sort_workspace_bytes(n)
   ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
   where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(ka), _ptr(va), _ptr(kb), _ptr(vb), n, 1 if iota else 0, begin_bit,
-                                            end_bit, _ptr(ws), nbytes, _stream()), "sort")
+                                            end_bit, _ptr(ws), nbytes, None, _stream()), "sort")
   k, v = (kb, vb) if where == 1 else (ka, va)
   return k.cpu().numpy().view(np.uint32)[:n], v.cpu().numpy().view(np.uint32)[:n]
 
 
-@pytest.mark.parametrize("n", [1, 255, 256, 257, 4096, 4097, 70_001, 3_000_000])
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 1024, 1025, 4096, 4097, 70_001, 3_000_000, 6_000_003])
 def test_radix_sort_full_keys_is_stable(n):
   rng = np.random.default_rng(n)
   keys = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
@@ -59,6 +59,72 @@ def test_radix_sort_full_keys_is_stable(n):
   order = np.argsort(keys, kind="stable")
   assert np.array_equal(k, keys[order])
   assert np.array_equal(v, order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("n,distinct", [(1_000_000, 1), (1_000_000, 3), (4_500_000, 2), (777_777, 300)])
+def test_radix_sort_few_distinct_keys(n, distinct):
+  """Every block holds the same few digits (long runs per digit, most histogram bins empty)."""
+  rng = np.random.default_rng(distinct)
+  pool = rng.integers(0, 2 ** 32, size=distinct, dtype=np.uint64).astype(np.uint32)
+  keys = pool[rng.integers(0, distinct, size=n)]
+  k, v = _sort(keys, 0, 32)
+  order = np.argsort(keys, kind="stable")
+  assert np.array_equal(k, keys[order])
+  assert np.array_equal(v, order.astype(np.uint32))
+
+
+def test_radix_sort_repeated_calls_reuse_one_workspace():
+  """Nothing is assumed about the workspace's contents: a garbage-filled one is reused call after call."""
+  lib = _lib.load()
+  n = 300_000
+  rng = np.random.default_rng(5)
+  nbytes = lib.gsr_sort_workspace_bytes(n)
+  ws = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+  for rep in range(3):
+    keys = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    ka = torch.from_numpy(keys.view(np.int32)).cuda()
+    va, kb, vb = torch.zeros_like(ka), torch.zeros_like(ka), torch.zeros_like(ka)
+    where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(ka), _ptr(va), _ptr(kb), _ptr(vb), n, 1, 0, 32, _ptr(ws), nbytes,
+                                              None, _stream()), "sort")
+    k, v = (kb, vb) if where == 1 else (ka, va)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
+    assert np.array_equal(v.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("n,capacity", [(0, 5000), (1, 1024), (1000, 1025), (70_001, 100_000), (70_001, 70_001),
+                                        (3_000_000, 4_500_000), (99, 5_000_000)])
+def test_radix_sort_with_count_on_the_device(n, capacity):
+  """n_dev: the arrays hold `capacity` slots, the element count sits in device memory (the renderer enqueues its tile
+  sort before the pair count has reached the host); the first n outputs equal an exact-size sort, the slack is ignored."""
+  lib = _lib.load()
+  rng = np.random.default_rng(n + capacity)
+  keys = rng.integers(0, 2 ** 13, size=capacity, dtype=np.uint64).astype(np.uint32)    # slack holds plausible keys too
+  vals2 = rng.integers(0, 2 ** 32, size=capacity, dtype=np.uint64).astype(np.uint32)
+  ka, v2a = torch.from_numpy(keys.view(np.int32)).cuda(), torch.from_numpy(vals2.view(np.int32)).cuda()
+  va, kb, vb, v2b = (torch.zeros_like(ka) for _ in range(4))
+  count = torch.tensor([n], dtype=torch.int32, device="cuda")
+  nbytes = lib.gsr_sort_workspace_bytes(capacity)
+  ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+  where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(ka), _ptr(va), _ptr(v2a), _ptr(kb), _ptr(vb), _ptr(v2b), capacity, 1, 0, 13,
+                                             _ptr(ws), nbytes, _ptr(count), _stream()), "sort2 counted")
+  k, v, v2 = (kb, vb, v2b) if where == 1 else (ka, va, v2a)
+  order = np.argsort(keys[:n], kind="stable")
+  assert np.array_equal(k.cpu().numpy().view(np.uint32)[:n], keys[:n][order])
+  assert np.array_equal(v.cpu().numpy().view(np.uint32)[:n], order.astype(np.uint32))
+  assert np.array_equal(v2.cpu().numpy().view(np.uint32)[:n], vals2[:n][order])
+  # tile ranges over the counted prefix only
+  num_tiles = 1 << 13
+  rng_out = torch.zeros(num_tiles, 2, dtype=torch.int32, device="cuda")
+  _lib.check(lib.gsr_tile_ranges(_ptr(k), capacity, num_tiles, _ptr(rng_out), _ptr(count), _stream()), "ranges counted")
+  got = rng_out.cpu().numpy()
+  sk = keys[:n][order]
+  want = np.zeros((num_tiles, 2), dtype=np.int32)
+  if n:
+    starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]])
+    ends = np.r_[starts[1:], n]
+    want[sk[starts], 0], want[sk[starts], 1] = starts, ends
+  assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("bits", [1, 7, 8, 13, 15, 20])
@@ -76,8 +142,8 @@ def test_radix_sort_partial_bits_keeps_input_order(bits):
 def test_sort_rejects_bad_arguments():
   lib = _lib.load()
   t = torch.zeros(16, dtype=torch.int32, device="cuda")
-  assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 40, _ptr(t), 64, _stream()) == -1
-  assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 32, _ptr(t), 8, _stream()) == -2
+  assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 40, _ptr(t), 64, None, _stream()) == -1
+  assert lib.gsr_sort_pairs_u32(_ptr(t), _ptr(t), _ptr(t), _ptr(t), 16, 1, 0, 32, _ptr(t), 8, None, _stream()) == -2
 
 
 @pytest.mark.parametrize("n,bits", [(1, 13), (1023, 13), (200_003, 13), (5_000_011, 15)])
@@ -93,7 +159,7 @@ def test_radix_sort_two_values(n, bits):
   nbytes = lib.gsr_sort_workspace_bytes(n)
   ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
   where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(ka), _ptr(va), _ptr(v2a), _ptr(kb), _ptr(vb), _ptr(v2b), n, 1, 0, bits,
-                                             _ptr(ws), nbytes, _stream()), "sort2")
+                                             _ptr(ws), nbytes, None, _stream()), "sort2")
   k, v, v2 = (kb, vb, v2b) if where == 1 else (ka, va, v2a)
   order = np.argsort(keys, kind="stable")
   assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])

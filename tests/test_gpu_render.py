@@ -463,6 +463,43 @@ def test_sh_factor_exchange_equals_gradient_sum():
     assert rel_err(pb[i].grad, pa[i].grad) < 1e-5              # Jacobian) may differ in the last bit of a colour
 
 
+def test_speculative_emit_and_early_colours_do_not_change_results():
+  """The pair emit runs into buffers sized from earlier frames before the overlap total is known, and the SH colours run
+  before the visible count is known: a frame must come out bit-identical whether the guess was absent (first frame of a
+  thread), too small (re-emit) or generous, and the three-call form (no early colours) must agree with the one-call form."""
+  from splat_trainer_amd import renderer
+  small = small_scene(400, 64, 48, sh_degree=1, seed=3, sigma_px=2.0)
+  large = small_scene(6000, 160, 120, sh_degree=1, seed=4, sigma_px=4.0)
+  keys = ("image", "visibility", "prune_cost", "split_score") + GRADS
+
+  def run(scene):
+    out = hip_render_and_grads(*scene, CFG, use_sh=True)
+    return {k: out[k].clone() for k in keys}, out["num_overlaps"]
+
+  renderer._TLS.__dict__.pop("overlap_guess", None)             # no guess: the emit waits for the total
+  first_small, o_small = run(small)
+  assert renderer._TLS.overlap_guess[0] >= o_small
+  first_large, o_large = run(large)                             # guess from the small frame is too small: emits again
+  assert o_large > o_small + o_small // 4 + 4096
+  again_small, _ = run(small)                                   # generous guess: narrowed views of larger buffers
+  again_large, _ = run(large)
+  for k in keys:
+    assert torch.equal(first_small[k], again_small[k]), k
+    assert torch.equal(first_large[k], again_large[k]), k
+
+  # three separate calls (evaluate_sh_at launched by itself, after the count is known)
+  g, cam = large
+  gd = sta.Gaussians3D(*(t.clone().cuda().requires_grad_(True) for t in (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+  camd = cam.to("cuda")
+  g2d, depth, idx = sta.project_to_image(gd, camd, CFG)
+  feats = sta.evaluate_sh_at(gd.feature, gd.position, idx, camd.camera_position)
+  r = sta.render_projected(idx, g2d, feats, depth, camd, CFG)
+  ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+  assert torch.equal(r.image.detach(), first_large["image"])
+  assert torch.equal(gd.feature.grad, first_large["d_feature"])
+  assert torch.equal(gd.position.grad, first_large["d_position"])
+
+
 def test_overlap_count_overflow_is_reported_not_wrapped():
   """A few thousand screen-filling splats at 4K: sum of tile overlaps > 2^32.  The u32 scan would wrap to a small number
   and the sort / composite buffers would be undersized; the guarded scan raises instead (renderer.py, host sync #2)."""

@@ -103,11 +103,12 @@ int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_wor
 /* ---- K2 3D->2D projection forward / backward  (project_to_image, second half) --------------------------- */
 /* gaussians2d_out: [M,6] = u v A B C opacity; depth_out: [M].  count_dev (may be NULL): device word holding the
  * true number of valid entries of ``indexes`` (<= M); lets the call be enqueued right behind gsr_frustum_cull,
- * before the host has read the count back. */
+ * before the host has read the count back.  depth_keys_out (may be NULL): [M] the depth sort's keys, exactly what
+ * gsr_depth_keys would derive from depth_out (saves that launch when the caller rasterizes next). */
 int gsr_project_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                         const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
-                        float* depth_out, const uint32_t* count_dev, void* stream);
+                        float* depth_out, const uint32_t* count_dev, uint32_t* depth_keys_out, void* stream);
 /* Rows ``indexes`` of the N-sized gradient tensors are written (accumulate = 0: other rows untouched, pass
  * zeros) or added to (accumulate = 1: "+=" straight into the caller's .grad buffers; rows are unique, no atomics). */
 int gsr_project_backward(const float* position, const float* log_scaling, const float* rotation_xyzw,
@@ -300,11 +301,13 @@ int gsr_compact_columns(const uint8_t* keep_mask, int64_t N, const uint32_t* blo
  * split_score[i] = exp_lerp(split_alpha, ., split_score[m]);  prune_cost[i] = exp_lerp(prune_alpha, ., prune_cost[m]).
  * idx rows are unique (one camera; NULL = rows are the points 0..M-1); the state arrays have N entries (points_in_view
  * int16).  Each input group is optional: a NULL screen_scale / visibility / split_score / prune_cost leaves the
- * corresponding state untouched (the data-parallel exchange replays only the two EMAs per camera and reduces the rest). */
+ * corresponding state untouched (the data-parallel exchange replays only the two EMAs per camera and reduces the rest).
+ * visible_sum (may be NULL): a second N-sized accumulator that also receives += visibility on the same rows -- the
+ * scene's own `visible` statistic (mlp_scene.py:244), so that it does not cost an index_add launch of its own. */
 int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t scale_cols, const float* visibility,
                         const float* split_score, const float* prune_cost, int64_t M, float split_alpha,
                         float prune_alpha, float* state_prune_cost, float* state_split_score, float* state_max_scale_px,
-                        int16_t* state_points_in_view, float* state_visibility, void* stream);
+                        int16_t* state_points_in_view, float* state_visibility, float* visible_sum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,7 @@ PROTOTYPES = {
     "gsr_sort_pairs2_u32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p, _p]),
     "gsr_cull_workspace_bytes": (_sz, [_i64]),
     "gsr_frustum_cull": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _sz, _p]),
-    "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p]),
+    "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p]),
     "gsr_project_backward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "gsr_sh_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p]),
@@ -90,7 +90,7 @@ PROTOTYPES = {
     "gsr_compact_workspace_bytes": (_sz, [_i64]),
     "gsr_compact_offsets": (C.c_int, [_p, _i64, _p, _p, _p, _sz, _p]),
     "gsr_compact_columns": (C.c_int, [_p, _i64, _p, _i64, _i64, C.POINTER(GsrColumnC), _i32, _p]),
-    "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
 }

@@ -36,14 +36,17 @@ class PointState:
     z = lambda dt=torch.float32: torch.zeros(num_points, dtype=dt, device=device)
     return PointState(z(), z(), z(), z(torch.int16), z())
 
-  def add_rendering(self, rendering, split_alpha: float = 0.01, prune_alpha: float = 0.1):
+  def add_rendering(self, rendering, split_alpha: float = 0.01, prune_alpha: float = 0.1, visible_sum=None):
     """point_state.py:34-50.  On the device the five updates run as one fused launch (densify.point_state_add); on the
-    CPU (the oracle side of the mask-parity tests) as the reference's torch ops below."""
+    CPU (the oracle side of the mask-parity tests) as the reference's torch ops below.  ``visible_sum``: the scene's
+    ``visible`` accumulator (mlp_scene.py:244, ``+= visibility`` on the same rows), folded into the same launch."""
     points = rendering.points
     if self.prune_cost.is_cuda:
       from .densify import point_state_add
-      point_state_add(self, points, split_alpha, prune_alpha)
+      point_state_add(self, points, split_alpha, prune_alpha, visible_sum=visible_sum)
       return
+    if visible_sum is not None:
+      visible_sum.index_add_(0, points.idx, points.visibility)
     image_scale_px = points.screen_scale.max(1).values
     self.max_scale_px[points.idx] = torch.maximum(self.max_scale_px[points.idx], image_scale_px)
     self.points_in_view[points.visible.idx] += 1

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(DN_THREADS) void point_state_add_kernel(const int64
                                                                      float* __restrict__ st_split,
                                                                      float* __restrict__ st_scale,
                                                                      int16_t* __restrict__ st_views,
-                                                                     float* __restrict__ st_vis) {
+                                                                     float* __restrict__ st_vis,
+                                                                     float* __restrict__ visible_sum) {
   const int64_t m = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
   if (m >= M) return;
   const int64_t i = idx ? idx[m] : m;             // rows of one camera are unique: no two threads share a point
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(DN_THREADS) void point_state_add_kernel(const int64
     const float v = vis[m];
     if (v > 0.f) st_views[i] = (int16_t)(st_views[i] + 1);
     st_vis[i] += v;
+    if (visible_sum) visible_sum[i] += v;         // the scene's own `visible` accumulator (mlp_scene.py:244), same rows
   }
   if (split) st_split[i] = exp_lerp(split_alpha, st_split[i], split[m]);
   if (prune) st_prune[i] = exp_lerp(prune_alpha, st_prune[i], prune[m]);
@@ -233,7 +235,7 @@ extern "C" {
 int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t scale_cols, const float* visibility,
                         const float* split_score, const float* prune_cost, int64_t M, float split_alpha,
                         float prune_alpha, float* state_prune_cost, float* state_split_score, float* state_max_scale_px,
-                        int16_t* state_points_in_view, float* state_visibility, void* stream_) {
+                        int16_t* state_points_in_view, float* state_visibility, float* visible_sum, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || (scale_cols != 1 && scale_cols != 2)) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
@@ -242,7 +244,7 @@ int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t s
     return GSR_ERR_INVALID_ARGUMENT;
   point_state_add_kernel<<<dn_grid(M, DN_THREADS), DN_THREADS, 0, stream>>>(
       idx, screen_scale, scale_cols, visibility, split_score, prune_cost, M, split_alpha, prune_alpha, state_prune_cost,
-      state_split_score, state_max_scale_px, state_points_in_view, state_visibility);
+      state_split_score, state_max_scale_px, state_points_in_view, state_visibility, visibility ? visible_sum : nullptr);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -98,17 +98,18 @@ def compact_rows(keep_mask: torch.Tensor, columns: Sequence[Tuple[torch.Tensor, 
   return outs
 
 
-def point_state_add(state, points, split_alpha: float = 0.01, prune_alpha: float = 0.1):
+def point_state_add(state, points, split_alpha: float = 0.01, prune_alpha: float = 0.1, visible_sum=None):
   """``PointState.add_rendering`` (splat_trainer/controller/point_state.py:34-50) for one camera in one launch, in place
   on the state's device tensors.  ``points``: RenderedPoints (idx, screen_scale (M,2) or (M,), visibility, split_score,
-  prune_cost)."""
+  prune_cost).  ``visible_sum``: optional second (N,) accumulator that receives ``+= visibility`` on the same rows (the
+  scene's ``visible`` statistic, mlp_scene.py:244)."""
   return point_state_update(state, points.idx, screen_scale=points.screen_scale, visibility=points.visibility,
                             split_score=points.split_score, prune_cost=points.prune_cost, split_alpha=split_alpha,
-                            prune_alpha=prune_alpha)
+                            prune_alpha=prune_alpha, visible_sum=visible_sum)
 
 
 def point_state_update(state, idx, screen_scale=None, visibility=None, split_score=None, prune_cost=None,
-                       split_alpha: float = 0.01, prune_alpha: float = 0.1):
+                       split_alpha: float = 0.01, prune_alpha: float = 0.1, visible_sum=None):
   """The fused update with every input group optional (``None`` leaves that part of the state alone); ``idx = None``:
   the rows are the points 0..M-1.  The data-parallel exchange uses it to replay only the two order-dependent EMAs per
   camera (distributed.exchange_point_stats)."""
@@ -127,9 +128,13 @@ def point_state_update(state, idx, screen_scale=None, visibility=None, split_sco
       raise _lib.GsplatHipError("point_state_update needs contiguous float32 CUDA state tensors (no CPU fallback)")
   if state.points_in_view.dtype != torch.int16:
     raise ValueError("points_in_view must be int16 (point_state.py:27)")
+  if visible_sum is not None and not (visible_sum.is_cuda and visible_sum.dtype == torch.float32 and
+                                      visible_sum.is_contiguous() and visible_sum.shape == state.visibility.shape):
+    raise ValueError("visible_sum must be a contiguous float32 CUDA tensor shaped like state.visibility")
   _lib.check(lib.gsr_point_state_add(_p(idx.contiguous()) if idx is not None else None, _p(scale), cols,
                                      _p(f32(visibility)), _p(f32(split_score)), _p(f32(prune_cost)), M,
                                      float(split_alpha), float(prune_alpha), _p(state.prune_cost), _p(state.split_score),
-                                     _p(state.max_scale_px), _p(state.points_in_view), _p(state.visibility), _stream()),
+                                     _p(state.max_scale_px), _p(state.points_in_view), _p(state.visibility),
+                                     _p(visible_sum), _stream()),
              "gsr_point_state_add")
   return state

@@ -46,16 +46,20 @@ class GradBucket:
     sizes = [p.numel() for p in self.params]
     align = 64                                        # floats: every view starts on a 256-byte boundary (the
     starts, off = [], 0                               # kernels use 16-byte vector accesses on gradient rows)
-    for n in sizes + [extra]:
+    # the extra columns come FIRST: with the (large, last) feature gradient exempt from the zero-fill, everything that
+    # does need zeroing is then one contiguous range -- one fill launch per batch instead of two
+    for n in [extra] + sizes:
       starts.append(off)
       off += ((n + align - 1) // align) * align
     total = off
     self.padded = ((total + self.world_size - 1) // self.world_size) * self.world_size
     dev = self.params[0].device
     self.flat = torch.zeros(self.padded, dtype=torch.float32, device=dev)
+    self.extra = self.flat[:extra]                    # e.g. the per-point `visible` accumulator
+    starts = starts[1:]
     self.views = [self.flat[o:o + n].view_as(p) for p, n, o in zip(self.params, sizes, starts)]
-    self.extra = self.flat[starts[-1]:starts[-1] + extra]   # e.g. the per-point `visible` accumulator
     self._starts = starts
+    self._used = starts[-1] + sizes[-1] if sizes else extra        # alignment / world-size padding behind it is never read
     self.attach()
 
   def attach(self):
@@ -75,7 +79,7 @@ class GradBucket:
       if lo > at:
         self.flat[at:lo].zero_()
       at = hi
-    if at < self.flat.numel():
+    if at < self._used:
       self.flat[at:].zero_()
 
   def all_reduce(self, group=None, mode: str = "all_reduce", async_op: bool = False):
@@ -414,10 +418,11 @@ class CameraShardedStep:
         accumulate_local_stats(r.points, self.scale_max, self.bucket.extra[:N], self.bucket.extra[N:])
         local.append(dict(camera=j, idx=r.points.idx, split_score=r.points.split_score, prune_cost=r.points.prune_cost))
         continue
+      if light:                                 # one rank: the reference's own loop; mlp_scene.py:244 rides in the launch
+        point_state.add_rendering(r, visible_sum=self.bucket.extra[:N])
+        continue
       self.bucket.extra[:N].index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
-      if light:
-        point_state.add_rendering(r)                                               # one rank: the reference's own loop
-      elif self.with_stats:
+      if self.with_stats:
         local.append(point_stats_of(j, r.points))
     if self.world == 1:
       return [] if light else local

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -121,6 +122,9 @@ def frustum_cull(position: torch.Tensor, camera_params: CameraParams, config: Ra
 
 # ------------------------------------------------------------------------------- data-dependent sizes
 _TLS = threading.local()
+# GSPLAT_HIP_NO_SPECULATION=1: enqueue nothing before the size it depends on has reached the host (A/B measurements;
+# results are bit-identical either way, tests/test_gpu_render.py::test_speculative_emit_and_early_colours_do_not_change_results)
+SPECULATE = os.environ.get("GSPLAT_HIP_NO_SPECULATION", "0") != "1"
 
 
 def _start_readback(words: torch.Tensor):
@@ -186,11 +190,12 @@ class _ProjectFn(torch.autograd.Function):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     g2d_full = torch.empty(N, 6, dtype=torch.float32, device=dev)
     depth_full = torch.empty(N, 1, dtype=torch.float32, device=dev)
+    keys_full = _u32(N, dev) if prefetch is not None else None     # the depth sort's keys, when the caller rasterizes next
     _lib.check(lib.gsr_frustum_cull(_ptr(pos), N, _ptr(T), _ptr(proj), W, H, near, far, margin, _ptr(indexes_full),
                                     _ptr(count), _ptr(ws), ws_bytes, stream), "gsr_frustum_cull")
     _lib.check(lib.gsr_project_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes_full), N, _ptr(T),
                                        _ptr(proj), C.byref(params), _ptr(g2d_full), _ptr(depth_full), _ptr(count),
-                                       stream), "gsr_project_forward")
+                                       _ptr(keys_full), stream), "gsr_project_forward")
     wait = _start_readback(count)  # host sync #1 (K2 is already running)
     sh_job = prefetch.pop("sh", None) if prefetch is not None else None
     if sh_job is not None and N > 0:
@@ -204,7 +209,7 @@ class _ProjectFn(torch.autograd.Function):
     if prefetch is not None and M > 0:
       # the caller will rasterize next: the depth sort needs only `depth`, so it is enqueued now and runs while the host
       # works its way to render_projected (the GPU would otherwise idle behind the sync)
-      prefetch["order"] = _launch_depth_order(depth.reshape(-1), M)
+      prefetch["order"] = _launch_depth_order(depth.reshape(-1), M, keys=keys_full[:M])
     ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
     ctx.set_materialize_grads(False)       # an unused output (depth, usually) arrives as None, not as a zero-filled tensor
     ctx.params = params
@@ -274,15 +279,18 @@ def _u32(n: int, device) -> torch.Tensor:
   return torch.empty(max(n, 1), dtype=torch.int32, device=device)   # raw storage for uint32 arrays
 
 
-def _launch_depth_order(depth: torch.Tensor, M: int) -> torch.Tensor:
-  """depth keys + stable 32-bit radix sort of the M splats (ties keep ascending index); returns order (M,) int32."""
+def _launch_depth_order(depth: torch.Tensor, M: int, keys: Optional[torch.Tensor] = None) -> torch.Tensor:
+  """depth keys + stable 32-bit radix sort of the M splats (ties keep ascending index); returns order (M,) int32.
+  ``keys``: the keys when K2 has already written them (consumed as sort scratch)."""
   lib = _lib.load()
   dev = depth.device
   stream = _stream()
-  keys_a, keys_b, vals_a, vals_b = _u32(M, dev), _u32(M, dev), _u32(M, dev), _u32(M, dev)
+  keys_a = keys if keys is not None else _u32(M, dev)
+  keys_b, vals_a, vals_b = _u32(M, dev), _u32(M, dev), _u32(M, dev)
   sort_bytes = lib.gsr_sort_workspace_bytes(M)
   sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
-  _lib.check(lib.gsr_depth_keys(_ptr(depth), M, _ptr(keys_a), stream), "gsr_depth_keys")
+  if keys is None:
+    _lib.check(lib.gsr_depth_keys(_ptr(depth), M, _ptr(keys_a), stream), "gsr_depth_keys")
   where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, 32,
                                             _ptr(sort_ws), sort_bytes, None, stream), "gsr_sort_pairs_u32(depth)")
   return vals_b if where == 1 else vals_a
@@ -365,7 +373,20 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
   st.count = _u32(M, dev)
   st.offsets = _u32(M, dev)
-  total = torch.zeros(2, dtype=torch.int32, device=dev)          # [number of overlaps, overflow flag]
+  # Everything that must start at zero comes out of ONE zero-filled allocation (one fill launch per frame): the
+  # heuristics, the tile ranges, the segment counter, [number of overlaps, overflow flag] and the per-pair visibility.
+  # Its size depends on the pair count, which is only guessed at this point (see below); a frame without a guess, or
+  # one that outgrows it, pays a second fill.
+  guesses = _TLS.__dict__.setdefault("overlap_guess", {})
+  guess = guesses.get(dev.index, 0) if SPECULATE else 0
+  fixed_zeros = 2 * M + 2 * num_tiles + 4                        # ... + capacity floats of per-pair visibility
+
+  def zero_block(capacity):
+    return torch.zeros(fixed_zeros + (capacity if need_vis_partial else 0), dtype=torch.float32, device=dev)
+
+  zeros_guess = zero_block(guess) if guess > 0 else None
+  total = (zeros_guess[fixed_zeros - 2:fixed_zeros].view(torch.int32) if zeros_guess is not None else
+           torch.zeros(2, dtype=torch.int32, device=dev))         # [number of overlaps, overflow flag]
   _lib.check(lib.gsr_tile_count(_ptr(g2d), _ptr(depth), _ptr(feats), _ptr(st.order), M, C_, W, H,
                                 C.byref(st.params), _ptr(st.rec), _ptr(st.count), _ptr(st.screen_scale), stream),
              "gsr_tile_count")
@@ -375,7 +396,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
                                                 _ptr(scan_ws), scan_bytes, stream), "gsr_exclusive_scan_u32_checked")
   wait = _start_readback(total)  # host "sync" #2: the number of (tile, splat) overlaps
 
-  def rasterize(capacity: int, pairs_dev: Optional[torch.Tensor]):
+  def rasterize(capacity: int, pairs_dev: Optional[torch.Tensor], zeros: Optional[torch.Tensor] = None):
     """K4 emit -> K5 tile sort -> tile ranges -> segment plan -> K6 (+ per-splat visibility) into buffers holding
     ``capacity`` pairs.  With ``pairs_dev`` (the device word with the pair count) the capacity is only a bound: every
     kernel that needs the count reads it there, so the whole chain is enqueued before the count has reached the host."""
@@ -383,9 +404,8 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
                                  _ptr(trank_a), capacity, stream), "gsr_tile_emit")
     tkeys_b, tvals_a, tvals_b, trank_b = _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev)
-    # everything that must start at zero comes out of ONE zero-filled allocation (one fill launch instead of three)
-    n_vis = capacity if need_vis_partial else 0
-    zeros = torch.zeros(2 * M + 2 * num_tiles + 1 + n_vis, dtype=torch.float32, device=dev)
+    if zeros is None:
+      zeros = zero_block(capacity)
     heuristics(zeros[:2 * M].view(2, M))
     # K6 writes every pixel of every tile (an empty tile writes colour 0, T 1, last 0): no zero-fills needed
     image = torch.empty(H, W, C_, dtype=torch.float32, device=dev)
@@ -407,7 +427,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), capacity, num_tiles, _ptr(st.tile_range), _ptr(pairs_dev), stream),
                "gsr_tile_ranges")
 
-    st.vis_partial = zeros[2 * M + 2 * num_tiles + 1:] if need_vis_partial else None
+    st.vis_partial = zeros[fixed_zeros:] if need_vis_partial else None
     st.pair_vis = torch.empty(capacity, dtype=torch.float32, device=dev) if need_vis_partial else None
     st.segments = _plan_segments(st, num_tiles, capacity, pairs_dev, dev, stream,
                                  zeros[2 * M + 2 * num_tiles:2 * M + 2 * num_tiles + 1].view(torch.int32))
@@ -429,9 +449,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   # total is known: the GPU never waits for the host's round trip, and by the time the host looks at the total (after
   # the composite launch) it has long arrived.  Only a frame that outgrows the guess is run again, with exact sizes.
   # Nothing in the result depends on the guess: kernels take the pair count from the device and ignore the slack.
-  guesses = _TLS.__dict__.setdefault("overlap_guess", {})
-  guess = guesses.get(dev.index, 0)
-  image = rasterize(guess, total[:1]) if guess > 0 else None
+  image = rasterize(guess, total[:1], zeros_guess) if guess > 0 else None
   O, overflow = wait()
   if overflow or O < 0:          # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
     raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
@@ -540,7 +558,8 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
     elif grad_out is not None:
       sh_out = (grad_out._check("feature", gaussians.feature), grad_out._check("position", gaussians.position), grad_out)
     camera_pos = camera_params.camera_position
-    if gaussians.feature.is_cuda and gaussians.feature.dim() == 3 and gaussians.feature.shape[2] in (1, 4, 9, 16):
+    if SPECULATE and gaussians.feature.is_cuda and gaussians.feature.dim() == 3 and \
+        gaussians.feature.shape[2] in (1, 4, 9, 16):
       # K3 rides behind K1 + K2 inside project_to_image, before the visible count has reached the host
       prefetch["sh"] = (gaussians.feature, gaussians.position, camera_pos,
                         _sh.wants_position_grad(gaussians.position, sh_out))

@@ -355,8 +355,10 @@ def main():
                                f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on",
                    "gaussians": N, "visible": M, "tile_overlaps": O, "pixels": P, "cameras_per_step": cameras_per_step,
                    "parallelism": ("dp1 (one GPU: gradients accumulate in place, no collective)" if world == 1 else
-                                   f"dp{world} (camera-sharded, all_reduce of {bucket.flat.numel() * 4 / 1e6:.0f} MB geometry "
-                                   f"grads + all_gather of {world * N * 12 / 1e6:.0f} MB colour-gradient factors)" if factor_mode else
+                                   f"dp{world} (camera-sharded; two collectives per step, no host sync: all_reduce of "
+                                   f"{bucket.flat.numel() * 4 / 1e6:.0f} MB geometry grads + sums, all_gather of {world} x "
+                                   f"{(6 * N + 3) * 4 / 1e6:.0f} MB per-camera blocks = colour-gradient factors + controller "
+                                   f"scores)" if factor_mode else
                                    f"dp{world} (camera-sharded, fused {args.collective} of {bucket.flat.numel() * 4 / 1e6:.0f} MB grads)"),
                    "parity": "parity unpinned by the reference (its rasterizer is an absent third-party package); "
                              "HIP vs this build's fp64 oracle is asserted by tests/ (-m gpu), observed errors in "

@@ -309,6 +309,26 @@ int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t s
                         float prune_alpha, float* state_prune_cost, float* state_split_score, float* state_max_scale_px,
                         int16_t* state_points_in_view, float* state_visibility, float* visible_sum, void* stream);
 
+/* ---- data-parallel exchange helpers (no reference counterpart: the reference is single-GPU) ------------- */
+/* One fixed-size block per camera, GSR_DP_BLOCK_FLOATS(N) = 6N + 3 floats: [0,3N) colour-gradient rows (0 where the
+ * camera saw nothing), [3N,3N+3) camera position, [3N+3,4N+3) split_score and [4N+3,5N+3) prune_cost (NaN where
+ * unseen), [5N+3,6N+3) larger screen-space sigma (0 where unseen).  The first 3N+3 floats are the per-camera input of
+ * gsr_sh_backward_multi.  gsr_dp_pack fills one block from a camera's rows (idx NULL: rows are the points 0..M-1);
+ * gsr_dp_replay applies the two order-dependent exp_lerp EMAs of PointState.add_rendering (point_state.py:49-50) for
+ * all cameras in camera order (slots[c] = block index of camera c) and folds the screen-scale maximum (:37).
+ * The two order-independent SUMS of the update ride along: gsr_dp_pack(visibility, visibility_sum, views_sum) adds this
+ * camera's visibility and its "saw the point" count to two N-sized accumulators (the extra columns of the gradient
+ * all-reduce); gsr_dp_replay(visibility_sum, views_sum, state_visibility, state_points_in_view) adds the all-reduced
+ * sums to the state (:40,43).  Pass NULL for the group to leave it out. */
+#define GSR_DP_BLOCK_FLOATS(N) (6 * (int64_t)(N) + 3)
+int gsr_dp_pack(const int64_t* idx, const float* dL_dcolors, const float* split_score, const float* prune_cost,
+                const float* screen_scale, int32_t scale_cols, const float* camera_pos, int64_t M, int64_t N,
+                float* block_out, const float* visibility, float* visibility_sum, float* views_sum, void* stream);
+int gsr_dp_replay(const float* blocks, int64_t stride, const int32_t* slots, int32_t num_cameras, int64_t N,
+                  float split_alpha, float prune_alpha, float* state_split_score, float* state_prune_cost,
+                  float* state_max_scale_px, const float* visibility_sum, const float* views_sum,
+                  float* state_visibility, int16_t* state_points_in_view, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

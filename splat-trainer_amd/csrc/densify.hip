@@ -228,6 +228,81 @@ __global__ __launch_bounds__(DN_THREADS) void point_state_add_kernel(const int64
   if (prune) st_prune[i] = exp_lerp(prune_alpha, st_prune[i], prune[m]);
 }
 
+
+// ---- data-parallel exchange: one dense block per camera (distributed.py: CameraShardedStep) -----------------------
+// Block layout (floats, N = points of the scene):  [0, 3N) colour-gradient rows r,g,b (0 where the camera saw nothing),
+// [3N, 3N+3) camera position, [3N+3, 4N+3) split_score and [4N+3, 5N+3) prune_cost (NaN where unseen),
+// [5N+3, 6N+3) larger screen-space sigma (0 where unseen).  Fixed size: no counts have to be exchanged first, so the
+// exchange needs no host round trip; the first 3N+3 floats are what gsr_sh_backward_multi reads.
+__global__ __launch_bounds__(DN_THREADS) void dp_fill_kernel(float* __restrict__ block, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (i >= 6 * N + 3) return;
+  const bool score = i >= 3 * N + 3 && i < 5 * N + 3;
+  block[i] = score ? __uint_as_float(0x7fc00000u) : 0.f;
+}
+
+__global__ __launch_bounds__(DN_THREADS) void dp_pack_kernel(const int64_t* __restrict__ idx,
+                                                             const float* __restrict__ dcol,
+                                                             const float* __restrict__ split,
+                                                             const float* __restrict__ prune,
+                                                             const float* __restrict__ scale, int scale_cols,
+                                                             const float* __restrict__ campos, int64_t M, int64_t N,
+                                                             float* __restrict__ block,
+                                                             const float* __restrict__ vis,
+                                                             float* __restrict__ vis_sum,
+                                                             float* __restrict__ views_sum) {
+  const int64_t m = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (m < 3) block[3 * N + m] = campos[m];
+  if (m >= M) return;
+  const int64_t i = idx ? idx[m] : m;
+  if (vis) {                                        // this rank's share of the two per-point SUMS (rows unique per camera)
+    const float v = vis[m];
+    vis_sum[i] += v;
+    if (v > 0.f) views_sum[i] += 1.f;
+  }
+  block[3 * i] = dcol[3 * m];
+  block[3 * i + 1] = dcol[3 * m + 1];
+  block[3 * i + 2] = dcol[3 * m + 2];
+  block[3 * N + 3 + i] = split[m];
+  block[4 * N + 3 + i] = prune[m];
+  float sc = scale[m * scale_cols];
+  if (scale_cols == 2) sc = fmaxf(sc, scale[m * 2 + 1]);
+  block[5 * N + 3 + i] = sc;
+}
+
+// Every rank replays the order-dependent EMAs of ALL cameras in camera order (slots[c] = block of camera c) and folds
+// the screen-scale maximum: one pass over the points instead of one launch per camera.
+__global__ __launch_bounds__(DN_THREADS) void dp_replay_kernel(const float* __restrict__ blocks, int64_t stride,
+                                                               const int32_t* __restrict__ slots, int num_cameras,
+                                                               int64_t N, float split_alpha, float prune_alpha,
+                                                               float* __restrict__ st_split,
+                                                               float* __restrict__ st_prune,
+                                                               float* __restrict__ st_scale,
+                                                               const float* __restrict__ vis_sum,
+                                                               const float* __restrict__ views_sum,
+                                                               float* __restrict__ st_vis,
+                                                               int16_t* __restrict__ st_views) {
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (i >= N) return;
+  if (vis_sum) {                                    // the two sums arrive all-reduced over the ranks
+    st_vis[i] += vis_sum[i];
+    st_views[i] = (int16_t)(st_views[i] + (int16_t)views_sum[i]);
+  }
+  float s = st_split[i], p = st_prune[i], mx = st_scale[i];
+  for (int c = 0; c < num_cameras; ++c) {
+    const float* b = blocks + (int64_t)slots[c] * stride;
+    const float v = b[3 * N + 3 + i];
+    if (v == v) {                                   // NaN: this camera did not see the point
+      s = exp_lerp(split_alpha, s, v);
+      p = exp_lerp(prune_alpha, p, b[4 * N + 3 + i]);
+    }
+    mx = fmaxf(mx, b[5 * N + 3 + i]);
+  }
+  st_split[i] = s;
+  st_prune[i] = p;
+  st_scale[i] = mx;
+}
+
 }  // namespace
 
 extern "C" {
@@ -245,6 +320,42 @@ int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t s
   point_state_add_kernel<<<dn_grid(M, DN_THREADS), DN_THREADS, 0, stream>>>(
       idx, screen_scale, scale_cols, visibility, split_score, prune_cost, M, split_alpha, prune_alpha, state_prune_cost,
       state_split_score, state_max_scale_px, state_points_in_view, state_visibility, visibility ? visible_sum : nullptr);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_dp_pack(const int64_t* idx, const float* dL_dcolors, const float* split_score, const float* prune_cost,
+                const float* screen_scale, int32_t scale_cols, const float* camera_pos, int64_t M, int64_t N,
+                float* block_out, const float* visibility, float* visibility_sum, float* views_sum, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || N < 3 || M > N || (scale_cols != 1 && scale_cols != 2) || !block_out || !camera_pos)
+    return GSR_ERR_INVALID_ARGUMENT;
+  if (visibility && (!visibility_sum || !views_sum)) return GSR_ERR_INVALID_ARGUMENT;
+  if (M > 0 && (!dL_dcolors || !split_score || !prune_cost || !screen_scale)) return GSR_ERR_INVALID_ARGUMENT;
+  if (M < N) {                                      // rows the camera did not see: zero gradient, NaN scores, zero scale
+    dp_fill_kernel<<<dn_grid(6 * N + 3, DN_THREADS), DN_THREADS, 0, stream>>>(block_out, N);
+    GSR_CHECK_LAUNCH();
+  }
+  dp_pack_kernel<<<dn_grid(M > 3 ? M : 3, DN_THREADS), DN_THREADS, 0, stream>>>(
+      idx, dL_dcolors, split_score, prune_cost, screen_scale, scale_cols, camera_pos, M, N, block_out, visibility,
+      visibility_sum, views_sum);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_dp_replay(const float* blocks, int64_t stride, const int32_t* slots, int32_t num_cameras, int64_t N,
+                  float split_alpha, float prune_alpha, float* state_split_score, float* state_prune_cost,
+                  float* state_max_scale_px, const float* visibility_sum, const float* views_sum,
+                  float* state_visibility, int16_t* state_points_in_view, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || num_cameras < 0 || stride < 6 * N + 3) return GSR_ERR_INVALID_ARGUMENT;
+  if (N == 0 || num_cameras == 0) return GSR_OK;
+  if (!blocks || !slots || !state_split_score || !state_prune_cost || !state_max_scale_px) return GSR_ERR_INVALID_ARGUMENT;
+  if (visibility_sum && (!views_sum || !state_visibility || !state_points_in_view)) return GSR_ERR_INVALID_ARGUMENT;
+  dp_replay_kernel<<<dn_grid(N, DN_THREADS), DN_THREADS, 0, stream>>>(blocks, stride, slots, num_cameras, N, split_alpha,
+                                                                     prune_alpha, state_split_score, state_prune_cost,
+                                                                     state_max_scale_px, visibility_sum, views_sum,
+                                                                     state_visibility, state_points_in_view);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

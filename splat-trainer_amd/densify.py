@@ -138,3 +138,77 @@ def point_state_update(state, idx, screen_scale=None, visibility=None, split_sco
                                      _p(visible_sum), _stream()),
              "gsr_point_state_add")
   return state
+
+
+# ------------------------------------------------------------------------------ data-parallel exchange blocks
+def dp_block_floats(num_points: int) -> int:
+  """Floats of one camera's exchange block (include/gsplat_hip.h: GSR_DP_BLOCK_FLOATS)."""
+  return 6 * int(num_points) + 3
+
+
+def dp_pack(block: torch.Tensor, num_points: int, idx: torch.Tensor, d_colour: torch.Tensor, split_score: torch.Tensor,
+            prune_cost: torch.Tensor, screen_scale: torch.Tensor, camera_pos: torch.Tensor,
+            visibility: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
+  """Fills one camera's fixed-size exchange block (layout in gsplat_hip.h) from the rows ``idx`` the camera saw: colour
+  gradient (0 elsewhere), camera position, split_score / prune_cost (NaN elsewhere), larger screen-space sigma (0
+  elsewhere).  One launch (two when the camera did not see every point).  ``visibility`` + ``sums`` (2 N floats): the
+  camera's visibility and its saw-the-point count are added to ``sums[:N]`` / ``sums[N:]`` in the same launch.  On CPU
+  tensors -- the gloo tests of the exchange logic -- the same is done with torch ops."""
+  N = int(num_points)
+  M = int(idx.shape[0])
+  if block.numel() != dp_block_floats(N) or block.dtype != torch.float32 or not block.is_contiguous():
+    raise ValueError("dp_pack: block must be a contiguous float32 tensor of 6 N + 3 elements")
+  f32 = lambda t: t.detach().to(torch.float32).contiguous()
+  scale = f32(screen_scale)
+  if not block.is_cuda:
+    block[:3 * N] = 0
+    block[3 * N + 3:5 * N + 3] = float("nan")
+    block[5 * N + 3:] = 0
+    block[:3 * N].view(N, 3).index_copy_(0, idx, f32(d_colour))
+    block[3 * N:3 * N + 3] = f32(camera_pos)
+    block[3 * N + 3:4 * N + 3].index_copy_(0, idx, f32(split_score))
+    block[4 * N + 3:5 * N + 3].index_copy_(0, idx, f32(prune_cost))
+    block[5 * N + 3:].index_copy_(0, idx, scale.max(1).values if scale.dim() == 2 else scale)
+    if visibility is not None:
+      sums[:N].index_add_(0, idx, f32(visibility))
+      sums[N:].index_add_(0, idx, (visibility > 0).to(torch.float32))
+    return block
+  lib = _lib.load()
+  cols = 2 if scale.dim() == 2 else 1
+  _lib.check(lib.gsr_dp_pack(_p(idx.contiguous()) if M < N else None, _p(f32(d_colour)), _p(f32(split_score)),
+                             _p(f32(prune_cost)), _p(scale), cols, _p(f32(camera_pos)), M, N, _p(block),
+                             _p(f32(visibility)) if visibility is not None else None,
+                             _p(sums[:N]) if visibility is not None else None,
+                             _p(sums[N:]) if visibility is not None else None, _stream()), "gsr_dp_pack")
+  return block
+
+
+def dp_replay(state, blocks: torch.Tensor, slots: torch.Tensor, num_points: int, split_alpha: float = 0.01,
+              prune_alpha: float = 0.1, sums: Optional[torch.Tensor] = None):
+  """Applies, for all cameras in camera order (``slots[c]`` = row of ``blocks`` holding camera c), the two
+  order-dependent EMAs of PointState.add_rendering to the rows each camera saw and folds the screen-scale maximum --
+  one pass over the points.  ``sums`` (2 N floats, all-reduced over the ranks): visibility and saw-the-point counts of
+  the batch, added to ``state.visibility`` / ``state.points_in_view`` in the same pass."""
+  N = int(num_points)
+  if blocks.dim() != 2 or blocks.shape[1] < dp_block_floats(N) or not blocks.is_contiguous():
+    raise ValueError("dp_replay: blocks must be (slots, >= 6 N + 3) contiguous")
+  if not blocks.is_cuda:
+    from .controller_math import exp_lerp
+    for s in slots.tolist():
+      b = blocks[s]
+      split, prune = b[3 * N + 3:4 * N + 3], b[4 * N + 3:5 * N + 3]
+      seen = ~torch.isnan(split)
+      state.split_score[seen] = exp_lerp(split_alpha, state.split_score[seen], split[seen])
+      state.prune_cost[seen] = exp_lerp(prune_alpha, state.prune_cost[seen], prune[seen])
+      torch.maximum(state.max_scale_px, b[5 * N + 3:6 * N + 3], out=state.max_scale_px)
+    if sums is not None:
+      state.visibility += sums[:N]
+      state.points_in_view += sums[N:].to(state.points_in_view.dtype)
+    return state
+  lib = _lib.load()
+  _lib.check(lib.gsr_dp_replay(_p(blocks), int(blocks.shape[1]), _p(slots), int(slots.shape[0]), N, float(split_alpha),
+                               float(prune_alpha), _p(state.split_score), _p(state.prune_cost), _p(state.max_scale_px),
+                               _p(sums[:N]) if sums is not None else None, _p(sums[N:]) if sums is not None else None,
+                               _p(state.visibility) if sums is not None else None,
+                               _p(state.points_in_view) if sums is not None else None, _stream()), "gsr_dp_replay")
+  return state

@@ -11,11 +11,14 @@ message is ONE large contiguous buffer that RCCL can split over all links/channe
 per-tensor calls each bound by launch latency: all gradients are packed into one contiguous fp32 buffer
 (padded to a multiple of world_size; 120 MB at 500k splats/SH3, 708 MB at 3M).
 
-ONE default everywhere (``DEFAULT_COLLECTIVE = "sh_factor"``, used by bench.py and ``CameraShardedStep``): a fused
-all-reduce of the geometry gradients + visible accumulator (12 floats per splat), an all-gather of the per-camera
-colour-gradient factors (3 floats per visible splat) from which every rank rebuilds the SH coefficient gradient, and
-an all-gather of the per-camera controller statistics (5 floats per visible splat), both packed to the largest
-visible count of the batch.  ``"all_reduce"`` (the whole 59-float buffer in one fused all-reduce) and
+ONE default everywhere (``DEFAULT_COLLECTIVE = "sh_factor"``, used by bench.py and ``CameraShardedStep``): TWO
+collectives per batch and no host round trip -- a fused all-reduce of the geometry gradients + visible accumulator +
+in-view count (13 floats per splat), and ONE all-gather of a fixed-size block per camera (6 floats per point: the
+colour-gradient factors from which every rank rebuilds the SH coefficient gradient, the two order-dependent controller
+scores, the screen-scale maximum; csrc/densify.hip: dp_pack / dp_replay).  The block is dense over the N points, so
+its size is known without exchanging visible counts first; ``packed=True`` selects the older form that pads to the
+largest visible count of the batch (smaller messages once the frustum cull removes most of the scene, at the price
+of a count exchange and a host sync per batch).  ``"all_reduce"`` (the whole 59-float buffer in one fused all-reduce) and
 ``"reduce_scatter"`` (``reduce_scatter_tensor`` + ``all_gather_into_tensor`` on the same buffer; gloo falls back to
 all_reduce) stay selectable for comparison.  None could be timed on xGMI in this build environment (one GPU).
 """
@@ -82,10 +85,10 @@ class GradBucket:
     if at < self._used:
       self.flat[at:].zero_()
 
-  def all_reduce(self, group=None, mode: str = "all_reduce", async_op: bool = False):
+  def all_reduce(self, group=None, mode: str = "all_reduce", async_op: bool = False, even_single: bool = False):
     """Sums the buffer over the ranks.  ``async_op=True`` (all_reduce mode only) returns the work handle instead of
-    making the current stream wait."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    making the current stream wait.  ``even_single``: issue the collective on a one-rank group too (tests)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not even_single):
       return None
     ws = dist.get_world_size(group)
     if mode == "reduce_scatter" and dist.get_backend(group) != "gloo":
@@ -368,17 +371,24 @@ class CameraShardedStep:
   NAMES = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
 
   def __init__(self, params: Sequence[torch.Tensor], world_size: int, rank: int, group=None,
-               mode: str = DEFAULT_COLLECTIVE, with_stats: bool = True):
+               mode: str = DEFAULT_COLLECTIVE, with_stats: bool = True, packed: bool = False,
+               exchange_when_single: bool = False):
+    """``packed``: exchange rows padded to the batch's largest visible count instead of the dense per-point block
+    (needs a count exchange + host sync per batch).  ``exchange_when_single``: run the exchange even with one rank
+    (tests: packing, the collectives on a one-rank group, rebuild and replay on a single GPU)."""
     from .renderer import GradOut
     from .sh import ShFactorCollector
     self.params = list(params)
     self.world, self.rank, self.group, self.mode, self.with_stats = max(world_size, 1), rank, group, mode, with_stats
-    self.factor = mode == "sh_factor" and self.world > 1
+    self.packed = packed
+    self.exchange = self.world > 1 or exchange_when_single
+    self.factor = mode == "sh_factor" and self.exchange
+    self._slots = {}
     N = self.params[0].shape[0]
     # extra: [visible accumulator (mlp_scene.py:244) | number of cameras that saw the point] -- both sums, so they ride
     # in the gradient all-reduce; the screen-scale maximum needs a MAX all-reduce of its own
     self.bucket = GradBucket(self.params[:4] if self.factor else self.params, self.world, extra=2 * N)
-    self.scale_max = torch.zeros(N, dtype=torch.float32, device=self.params[0].device) if self.world > 1 else None
+    self.scale_max = torch.zeros(N, dtype=torch.float32, device=self.params[0].device) if self.exchange else None
     self.feature_grad = torch.empty_like(self.params[4]) if self.factor else None
     self.collector = ShFactorCollector() if self.factor else None
     v = self.bucket.views
@@ -404,17 +414,22 @@ class CameraShardedStep:
     N = position.shape[0]
     light = point_state is not None
     mine = shard_cameras(len(cameras), self.rank, self.world)
+    dense = self.factor and light and not self.packed
     if self.factor:
       self.bucket.zero()
     else:                                     # the first SH backward of the batch overwrites the feature gradient
       self.bucket.zero(except_views=(4,))
       self.grad_out.feature_uninitialized = True
     local = []
-    if light and self.world > 1:
+    if light and self.exchange and not dense:
       self.scale_max.zero_()
     for j in mine:
       r = render_backward(j, cameras[j], self.grad_out, self.collector)
-      if light and self.world > 1:
+      if dense:                               # sums ride in the all-reduce; scores + scale go into the camera's block
+        local.append(dict(camera=j, idx=r.points.idx, split_score=r.points.split_score, prune_cost=r.points.prune_cost,
+                          screen_scale=r.points.screen_scale, visibility=r.points.visibility))
+        continue
+      if light and self.exchange:
         accumulate_local_stats(r.points, self.scale_max, self.bucket.extra[:N], self.bucket.extra[N:])
         local.append(dict(camera=j, idx=r.points.idx, split_score=r.points.split_score, prune_cost=r.points.prune_cost))
         continue
@@ -424,8 +439,11 @@ class CameraShardedStep:
       self.bucket.extra[:N].index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
       if self.with_stats:
         local.append(point_stats_of(j, r.points))
-    if self.world == 1:
+    if not self.exchange:
       return [] if light else local
+    if dense:
+      self._exchange_dense(len(cameras), local, point_state)
+      return []
     cpr = (len(cameras) + self.world - 1) // self.world
     counts = exchange_counts([(d["camera"], d["idx"].shape[0]) for d in local] if (self.with_stats or light) else
                              [(j, it[0].shape[0]) for j, it in zip(mine, self.collector.items)] if self.factor else
@@ -447,3 +465,71 @@ class CameraShardedStep:
     if not self.with_stats:
       return []
     return gather_point_stats(local, len(cameras), group=self.group, device=dev, counts=counts)
+
+  # ------------------------------------------------------------------------------------------ dense exchange
+  def camera_slots(self, num_cameras: int, device) -> torch.Tensor:
+    """Row of the gathered block that holds camera c, for c = 0..num_cameras-1 (camera j lives on rank j mod world, in
+    that rank's slot j // world; the gather is rank-major)."""
+    key = (num_cameras, str(device))
+    if key not in self._slots:
+      cpr = (num_cameras + self.world - 1) // self.world
+      self._slots[key] = torch.tensor([(j % self.world) * cpr + j // self.world for j in range(num_cameras)],
+                                      dtype=torch.int32, device=device)
+    return self._slots[key]
+
+  def pack_camera_blocks(self, num_cameras: int, local: List[dict], factors: Sequence) -> torch.Tensor:
+    """This rank's cameras as fixed-size blocks (densify.dp_pack), (cameras_per_rank, 6 N + 3).  ``factors``: the SH
+    collector's items (idx, d_colour, camera position) in the order of ``local``; a ``visibility`` entry in a ``local``
+    dict also adds that camera to the two sum columns of the gradient bucket (visible accumulator | in-view count).
+    Unused slots carry an empty camera (zero gradient, NaN scores)."""
+    from .densify import dp_block_floats, dp_pack
+    position = self.params[0]
+    N, dev = position.shape[0], position.device
+    cpr = (num_cameras + self.world - 1) // self.world
+    send = torch.empty(cpr, dp_block_floats(N), dtype=torch.float32, device=dev)
+    empty_i = torch.empty(0, dtype=torch.int64, device=dev)
+    empty_f = torch.empty(0, dtype=torch.float32, device=dev)
+    for s in range(cpr):
+      if s < len(local):
+        d, (idx, d_colour, cam) = local[s], factors[s]
+        dp_pack(send[s], N, idx, d_colour, d["split_score"], d["prune_cost"], d["screen_scale"], cam,
+                visibility=d.get("visibility"), sums=self.bucket.extra)
+      else:
+        dp_pack(send[s], N, empty_i, empty_f.view(0, 3), empty_f, empty_f, empty_f.view(0, 2),
+                torch.zeros(3, dtype=torch.float32, device=dev))
+    return send
+
+  def all_gather_blocks(self, send: torch.Tensor) -> torch.Tensor:
+    """(world * cameras_per_rank, 6 N + 3) block table, rank-major, identical on every rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+      return send
+    recv = torch.empty(self.world * send.shape[0], send.shape[1], dtype=torch.float32, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=self.group)
+    return recv
+
+  def _exchange_dense(self, num_cameras: int, local: List[dict], point_state):
+    """The default exchange: all-reduce (geometry gradients + visible + in-view count) in flight while the camera blocks
+    are packed and all-gathered; then every rank rebuilds the SH gradient of all cameras and replays their controller
+    scores in camera order.  Two collectives, no host sync."""
+    import ctypes as C
+    from . import _lib
+    from .densify import dp_replay
+    position, feature = self.params[0], self.params[4]
+    N, K = position.shape[0], feature.shape[2]
+    initialised = dist.is_available() and dist.is_initialized()
+    # pack first: it also adds this rank's cameras to the two sum columns the all-reduce carries
+    send = self.pack_camera_blocks(num_cameras, local, self.collector.items)
+    pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True,
+                                     even_single=True) if initialised else None
+    blocks = self.all_gather_blocks(send)
+    if pending is not None:
+      pending.wait()                                   # d_pos below adds to the all-reduced position gradient
+    width = blocks.shape[1]
+    base = blocks.data_ptr()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    _lib.check(_lib.load().gsr_sh_backward_multi(C.c_void_p(base), width, C.c_void_p(base + 4 * 3 * N), width,
+                                                 blocks.shape[0], ptr(feature.detach()), ptr(position.detach()), N, K,
+                                                 ptr(self.feature_grad), ptr(self.bucket.views[0]), 0,
+                                                 _lib.current_stream_ptr()), "gsr_sh_backward_multi")
+    self.collector.clear()
+    dp_replay(point_state, blocks, self.camera_slots(num_cameras, position.device), N, sums=self.bucket.extra)

@@ -30,7 +30,8 @@ from .controller_math import PointState, find_split_prune_indexes
 from .data_types import CameraParams, Gaussians3D, RasterConfig
 from .optim import ParameterClass, VisibilityAwareLaProp
 from .tensor_rows import TensorRows
-from .renderer import render_gaussians
+from .loss import clamped_mse_loss
+from .renderer import GradOut, render_gaussians
 
 PARAM_NAMES = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
 
@@ -132,19 +133,37 @@ class MiniTrainer:
     pts.visible.zero_()
     pts.zero_grad()
 
+  def _grad_target(self) -> GradOut:
+    """The parameters' ``.grad`` tensors as the accumulation target of the backward kernels (renderer.GradOut): the
+    reference sums the cameras of a batch into ``.grad`` through autograd (trainer.py:500-514, zero_grad only in
+    scene.step); here the kernels add their rows straight into the same tensors, which spares every camera the dense
+    N-sized temporaries and autograd's accumulate pass over them.  The coefficient gradient -- 48 of the 59 floats per
+    point -- is not even zero-filled: the first camera's SH backward overwrites it row for row."""
+    grads = {}
+    for n in PARAM_NAMES:
+      p = self.points.tensors[n]
+      if p.grad is None or p.grad.shape != p.shape:
+        p.grad = torch.empty_like(p)
+      if n != "feature":
+        p.grad.zero_()
+      grads[n] = p.grad
+    return GradOut(feature_uninitialized=True, **grads)
+
   def training_step(self) -> float:
     """trainer.py:531-545: evaluate_backward_with over the batch, then the optimizer step."""
     total = 0.0
+    fused = self.device.type == "cuda"
+    grad_out = self._grad_target() if fused else None
     for cam, target in zip(self.cameras, self.targets):
       with torch.enable_grad():
-        r = render_gaussians(self.scene(), cam, self.config, use_sh=True)
+        r = render_gaussians(self.scene(), cam, self.config, use_sh=True, grad_out=grad_out)
         if r.points.num_visible == 0:
           raise RuntimeError("No visible points")                     # trainer.py:507-509
-        loss = F.mse_loss(r.image.clamp(0, 1), target)
+        loss = clamped_mse_loss(r.image, target) if fused else F.mse_loss(r.image.clamp(0, 1), target)
         loss.backward()
       with torch.no_grad():
-        self.state.add_rendering(r)                                    # point_state.py:34-50 (camera order)
-        self.points.visible[r.points.idx] += r.points.visibility       # mlp_scene.py:244
+        # point_state.py:34-50 (camera order) and mlp_scene.py:244 (visible[idx] += visibility) in one launch
+        self.state.add_rendering(r, visible_sum=self.points.visible)
       total += float(loss.item())
     self.optimizer_step()
     self.step_idx += 1

@@ -187,8 +187,20 @@ def _stats_worker(rank, world, port, out_path, num_cameras):
   for _ in range(2):                                             # two batches: the reductions must reset in between
     assert dp.run(list(range(num_cameras)), fake_render, point_state=light) == []
   fields = ("prune_cost", "split_score", "max_scale_px", "points_in_view", "visibility")
+  # the DEFAULT exchange (dense per-camera blocks, no counts): blocks packed, gathered and replayed; the rebuild kernel
+  # that consumes the colour-gradient part is HIP-only and checked on the GPU (tests/test_gpu_render.py)
+  from splat_trainer_amd.densify import dp_replay
+  dd = CameraShardedStep(params, world, rank)
+  loc = [dict(camera=j, idx=d["idx"], split_score=d["split_score"], prune_cost=d["prune_cost"],
+              screen_scale=torch.stack([d["screen_scale_max"], 0.5 * d["screen_scale_max"]], dim=1))
+         for j, d in ((j, _camera_stats(j, n)) for j in mine)]
+  blocks = dd.all_gather_blocks(dd.pack_camera_blocks(num_cameras, loc, col.items))
+  replayed = PointState.new_zeros(n, "cpu")
+  for _ in range(2):
+    dp_replay(replayed, blocks, dd.camera_slots(num_cameras, "cpu"), n)
   torch.save(dict(stats=got, masks=masks, state={f: getattr(state, f) for f in fields}, dense=dense, packed=packed,
-                  counts=counts, light={f: getattr(light, f) for f in fields}, visible=dp.visible.clone()),
+                  counts=counts, light={f: getattr(light, f) for f in fields}, visible=dp.visible.clone(),
+                  blocks=blocks, replayed={f: getattr(replayed, f) for f in fields}),
              f"{out_path}.{rank}")
   dist.barrier()
   dist.destroy_process_group()
@@ -247,3 +259,12 @@ def test_two_rank_point_stats_and_packed_factors(tmp_path, num_cameras):
     m2 = find_split_prune_indexes(PointState(**r["light"]), 0.2, 560, min_views=1, max_scale_px=50.0)
     want = find_split_prune_indexes(twice, 0.2, 560, min_views=1, max_scale_px=50.0)
     assert torch.equal(m2[0], want[0]) and torch.equal(m2[1], want[1])
+  # dense per-camera blocks: identical on both ranks, the factor part equals the dense factor gather, and the replayed
+  # order-dependent state equals the sequential loop's bit for bit
+  for r in (r0, r1):
+    b = r["blocks"]
+    assert b.shape == (r["dense"].shape[0], 6 * n + 3)
+    assert torch.equal(b[:, :3 * n + 3].reshape(-1, n + 1, 3), r["dense"])
+    assert torch.equal(torch.nan_to_num(b, nan=-1.0), torch.nan_to_num(r0["blocks"], nan=-1.0))
+    for f in ("prune_cost", "split_score", "max_scale_px"):
+      assert torch.equal(r["replayed"][f], getattr(twice, f)), f

@@ -1,0 +1,104 @@
+"""The default data-parallel exchange (distributed.CameraShardedStep: dense per-camera blocks, two collectives, no host
+sync) on one GPU: packing, RCCL's all-reduce / all-gather on a ONE-rank group, the SH-gradient rebuild over all
+cameras and the in-order replay of the controller statistics, against the sequential per-camera loop."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import splat_trainer_amd as sta
+from helpers import small_scene
+from splat_trainer_amd import synthetic
+from splat_trainer_amd.controller_math import PointState
+from splat_trainer_amd.densify import dp_block_floats, dp_pack, dp_replay
+from splat_trainer_amd.distributed import CameraShardedStep
+
+pytestmark = pytest.mark.gpu
+CFG = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+  yield
+  dist.destroy_process_group()
+
+
+def _scene(culled: bool):
+  if culled:
+    g, cams = synthetic.scene_b(20_000, 320, 240, sh_degree=2, seed=2, num_cameras=3, radius=1.2)   # frustum cull active
+  else:
+    g, cam = small_scene(3000, 160, 120, sh_degree=2, seed=9, sigma_px=3.0)
+    cams = [cam, sta.CameraParams(cam.T_camera_world.clone(), cam.projection * 1.0, cam.image_size, cam.near_plane, cam.far_plane)]
+    cams[1].T_camera_world[0, 3] += 0.05
+  return g, [c.to("cuda") for c in cams]
+
+
+def _run(g, cams, **step_options):
+  params = [t.clone().cuda().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+  scene = sta.Gaussians3D(position=params[0], rotation=params[2], log_scaling=params[1], alpha_logit=params[3], feature=params[4])
+  target = torch.full((cams[0].image_size[1], cams[0].image_size[0], 3), 0.5, device="cuda")
+
+  def render_backward(j, cam, grad_out, collector):
+    with torch.enable_grad():
+      r = sta.render_gaussians(scene, cam, CFG, use_sh=True, grad_out=grad_out, sh_collector=collector)
+      sta.clamped_mse_loss(r.image, target).backward()
+    return r
+
+  dp = CameraShardedStep(params, 1, 0, **step_options)
+  state = PointState.new_zeros(params[0].shape[0], "cuda")
+  for _ in range(2):                                     # two batches: everything per-batch must reset in between
+    dp.run(cams, render_backward, point_state=state)
+  return {k: v.clone() for k, v in dp.grads.items()}, state, dp.visible.clone()
+
+
+@pytest.mark.parametrize("culled", [False, True])
+def test_dense_exchange_on_one_rank_equals_the_sequential_loop(one_rank_group, culled):
+  g, cams = _scene(culled)
+  want_g, want_s, want_v = _run(g, cams)                                  # no exchange: the reference's own loop
+  got_g, got_s, got_v = _run(g, cams, exchange_when_single=True)          # dense blocks through RCCL (one rank)
+  for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view"):
+    assert torch.equal(getattr(got_s, f), getattr(want_s, f)), f          # what the densify masks are made of: bit-exact
+  assert torch.allclose(got_s.visibility, want_s.visibility, rtol=1e-6, atol=1e-7)
+  assert torch.allclose(got_v, want_v, rtol=1e-6, atol=1e-7)
+  for k in want_g:                                                        # same sums, different association order
+    scale = want_g[k].abs().max().clamp_min(1e-20)
+    assert (got_g[k] - want_g[k]).abs().max() / scale < 2e-5, k
+  assert want_s.points_in_view.max() >= 2 and want_s.split_score.abs().max() > 0
+
+
+def test_dp_pack_and_replay_match_their_cpu_forms():
+  n, m = 1000, 640
+  gen = torch.Generator().manual_seed(3)
+  idx = torch.randperm(n, generator=gen)[:m].sort().values
+  d = dict(dcol=torch.randn(m, 3, generator=gen), split=torch.rand(m, generator=gen), prune=torch.rand(m, generator=gen),
+           scale=torch.rand(m, 2, generator=gen) * 30, cam=torch.randn(3, generator=gen))
+  vis = torch.rand(m, generator=gen)
+  vis[::3] = 0.0
+  blocks, all_sums = [], []
+  for dev in ("cpu", "cuda"):
+    b = torch.full((2, dp_block_floats(n)), 7.0, device=dev)              # garbage: every float must be (re)written
+    sums = torch.ones(2 * n, device=dev)
+    dp_pack(b[0], n, idx.to(dev), d["dcol"].to(dev), d["split"].to(dev), d["prune"].to(dev), d["scale"].to(dev), d["cam"].to(dev),
+            visibility=vis.to(dev), sums=sums)
+    all_sums.append(sums)
+    full = torch.arange(n, device=dev)
+    dp_pack(b[1], n, full, torch.ones(n, 3, device=dev), torch.full((n,), 0.5, device=dev), torch.full((n,), 0.25, device=dev),
+            torch.full((n, 2), 2.0, device=dev), d["cam"].to(dev))
+    blocks.append(b)
+  assert torch.equal(torch.nan_to_num(blocks[0], nan=-1.0), torch.nan_to_num(blocks[1].cpu(), nan=-1.0))
+  assert torch.isnan(blocks[1][0, 3 * n + 3:5 * n + 3]).sum() == 2 * (n - m)
+  assert torch.equal(all_sums[0], all_sums[1].cpu())
+  assert all_sums[0][:n].sum() == pytest.approx(n + float(vis.sum()), rel=1e-5) and all_sums[0][n:].sum() == n + int((vis > 0).sum())
+  slots = torch.tensor([1, 0, 1], dtype=torch.int32)
+  states = []
+  for b, sums, dev in zip(blocks, all_sums, ("cpu", "cuda")):
+    st = PointState.new_zeros(n, dev)
+    dp_replay(st, b, slots.to(dev), n, sums=sums)
+    states.append(st)
+  assert torch.equal(states[0].points_in_view, states[1].points_in_view.cpu())
+  assert torch.equal(states[0].visibility, states[1].visibility.cpu())
+  for f in ("split_score", "prune_cost", "max_scale_px"):
+    assert torch.allclose(getattr(states[0], f), getattr(states[1], f).cpu(), rtol=2e-5, atol=2e-6), f   # expf/logf: host libm vs device

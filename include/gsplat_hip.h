@@ -104,11 +104,12 @@ int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_wor
 /* gaussians2d_out: [M,6] = u v A B C opacity; depth_out: [M].  count_dev (may be NULL): device word holding the
  * true number of valid entries of ``indexes`` (<= M); lets the call be enqueued right behind gsr_frustum_cull,
  * before the host has read the count back.  depth_keys_out (may be NULL): [M] the depth sort's keys, exactly what
- * gsr_depth_keys would derive from depth_out (saves that launch when the caller rasterizes next). */
+ * gsr_depth_keys(depth_out, bias, max_key) would give (saves that launch when the caller rasterizes next). */
 int gsr_project_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                         const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
-                        float* depth_out, const uint32_t* count_dev, uint32_t* depth_keys_out, void* stream);
+                        float* depth_out, const uint32_t* count_dev, uint32_t* depth_keys_out, uint32_t depth_key_bias,
+                        uint32_t depth_key_max, void* stream);
 /* Rows ``indexes`` of the N-sized gradient tensors are written (accumulate = 0: other rows untouched, pass
  * zeros) or added to (accumulate = 1: "+=" straight into the caller's .grad buffers; rows are unique, no atomics). */
 int gsr_project_backward(const float* position, const float* log_scaling, const float* rotation_xyzw,
@@ -155,8 +156,12 @@ int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, c
                           void* stream);
 
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */
-/* depth -> sortable u32 keys */
-int gsr_depth_keys(const float* depth, int64_t M, uint32_t* keys_out, void* stream);
+/* depth -> sortable u32 keys, key = min(bits(depth) - bias, max_key), monotone in depth.  gsr_depth_key_range gives
+ * (bias, max_key) for a camera's near / far planes: the keys of a frame then span only bits(far) - bits(near) -- 27
+ * bits for 0.1 .. 100 -- and gsr_sort_pairs_u32(0, bit length of max_key) needs three passes instead of four (9-bit
+ * digits).  bias 0 / max_key 0xFFFFFFFF (what the range call returns for a non-positive or infinite range): plain keys. */
+int gsr_depth_key_range(float near_plane, float far_plane, uint32_t* bias_out, uint32_t* max_key_out);
+int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_key, uint32_t* keys_out, void* stream);
 /* For rank k in depth order (order[k] = splat): writes the 12-float record rec[k] and the number of tiles its
  * support touches; also screen_scale_out[splat] = (sigma_major, sigma_minor) in pixels (sqrt of the eigenvalues
  * of the blurred 2D covariance).  features: [M,C], C in {1,2,3}. */

@@ -45,7 +45,7 @@ def raster_params(config) -> GsrRasterParamsC:
 
 
 _p = C.c_void_p
-_i64, _i32, _f, _sz = C.c_int64, C.c_int32, C.c_float, C.c_size_t
+_i64, _i32, _u32, _f, _sz = C.c_int64, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
 _pp = C.POINTER(GsrRasterParamsC)
 _ps = C.POINTER(GsrSegmentsC)
 
@@ -61,14 +61,15 @@ PROTOTYPES = {
     "gsr_sort_pairs2_u32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, C.c_int, _p, _sz, _p, _p]),
     "gsr_cull_workspace_bytes": (_sz, [_i64]),
     "gsr_frustum_cull": (C.c_int, [_p, _i64, _p, _p, _i32, _i32, _f, _f, _f, _p, _p, _p, _sz, _p]),
-    "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p]),
+    "gsr_project_forward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _u32, _u32, _p]),
     "gsr_project_backward": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "gsr_sh_forward": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "gsr_sh_backward": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p]),
     "gsr_sh_backward_multi": (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p]),
     "gsr_inverse_map": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "gsr_sh_backward_dense": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
-    "gsr_depth_keys": (C.c_int, [_p, _i64, _p, _p]),
+    "gsr_depth_key_range": (C.c_int, [_f, _f, _p, _p]),
+    "gsr_depth_keys": (C.c_int, [_p, _i64, _u32, _u32, _p, _p]),
     "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p]),
     "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p]),
     "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),

@@ -18,12 +18,10 @@ inline GsrRasterParams to_params(const GsrRasterParamsC* c) {
 inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
 __global__ __launch_bounds__(256) void depth_keys_kernel(const float* __restrict__ depth, int64_t M,
-                                                         uint32_t* __restrict__ keys) {
+                                                         uint32_t* __restrict__ keys, uint32_t bias, uint32_t max_key) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  // depth > near > 0 after the cull, so the IEEE bit pattern is monotone; guard the sign anyway
-  uint32_t b = __float_as_uint(depth[m]);
-  keys[m] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  keys[m] = gsr_depth_key(depth[m], bias, max_key);
 }
 
 __device__ __forceinline__ uint32_t count_tiles(float u, float v, float A, float B, float C, const GsrExtent& e) {
@@ -184,12 +182,26 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
 
 extern "C" {
 
-int gsr_depth_keys(const float* depth, int64_t M, uint32_t* keys_out, void* stream_) {
+int gsr_depth_key_range(float near_plane, float far_plane, uint32_t* bias_out, uint32_t* max_key_out) {
+  if (!bias_out || !max_key_out) return GSR_ERR_INVALID_ARGUMENT;
+  *bias_out = 0u;
+  *max_key_out = 0xFFFFFFFFu;
+  if (near_plane > 0.f && far_plane > near_plane && far_plane < 3.0e38f) {     // finite positive range: keys from 0
+    uint32_t lo, hi;
+    __builtin_memcpy(&lo, &near_plane, 4);
+    __builtin_memcpy(&hi, &far_plane, 4);
+    *bias_out = lo | 0x80000000u;
+    *max_key_out = hi - lo;
+  }
+  return GSR_OK;
+}
+
+int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_key, uint32_t* keys_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
   if (!depth || !keys_out) return GSR_ERR_INVALID_ARGUMENT;
-  depth_keys_kernel<<<grid_for(M, 256), 256, 0, stream>>>(depth, M, keys_out);
+  depth_keys_kernel<<<grid_for(M, 256), 256, 0, stream>>>(depth, M, keys_out, bias, max_key);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const float* __restric
                                                           GsrRasterParams rp, float* __restrict__ g2d,
                                                           float* __restrict__ depth,
                                                           const uint32_t* __restrict__ count_dev,
-                                                          uint32_t* __restrict__ depth_keys) {
+                                                          uint32_t* __restrict__ depth_keys, uint32_t key_bias,
+                                                          uint32_t key_max) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // M is an upper bound when count_dev is given: the true count is still on the device (K1 just produced it)
   if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
@@ -77,10 +78,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const float* __restric
   *reinterpret_cast<float2*>(g + 2) = make_float2(o.A, o.B);
   *reinterpret_cast<float2*>(g + 4) = make_float2(o.C, o.opacity);
   depth[m] = o.depth;
-  if (depth_keys) {                         // the depth sort's keys (binning.hip: depth_keys_kernel) while the value is at hand
-    const uint32_t b = __float_as_uint(o.depth);
-    depth_keys[m] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-  }
+  // the depth sort's keys (binning.hip: depth_keys_kernel) while the value is at hand
+  if (depth_keys) depth_keys[m] = gsr_depth_key(o.depth, key_bias, key_max);
 }
 
 template <bool ACC>
@@ -430,7 +429,8 @@ int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_wor
 int gsr_project_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
                         const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
                         const float* projection, const GsrRasterParamsC* params_host, float* gaussians2d_out,
-                        float* depth_out, const uint32_t* count_dev, uint32_t* depth_keys_out, void* stream_) {
+                        float* depth_out, const uint32_t* count_dev, uint32_t* depth_keys_out, uint32_t depth_key_bias,
+                        uint32_t depth_key_max, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
@@ -439,7 +439,8 @@ int gsr_project_forward(const float* position, const float* log_scaling, const f
     return GSR_ERR_INVALID_ARGUMENT;
   project_fwd_kernel<<<grid_for(M, 256), 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
                                                           T_camera_world, projection, to_params(params_host),
-                                                          gaussians2d_out, depth_out, count_dev, depth_keys_out);
+                                                          gaussians2d_out, depth_out, count_dev, depth_keys_out,
+                                                          depth_key_bias, depth_key_max);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

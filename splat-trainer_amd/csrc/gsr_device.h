@@ -75,6 +75,17 @@ __device__ __forceinline__ int gsr_mbcnt(uint64_t mask) {  // number of set bits
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
+// Depth -> sortable u32 key.  The IEEE bit pattern of a positive float is monotone (sign bit set keeps negatives, which
+// the cull never lets through, below); `bias` = key of the near plane makes the keys of a frame start at 0, so that
+// they span only bits(far) - bits(near) (27 bits for 0.1 .. 100) and the radix sort needs fewer passes.  Depths outside
+// [near, far] -- only possible for a caller-made depth tensor -- clamp to the ends (order among them: by index).
+__device__ __forceinline__ uint32_t gsr_depth_key(float depth, uint32_t bias, uint32_t max_key) {
+  const uint32_t b = __float_as_uint(depth);
+  const uint32_t k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  const uint32_t rel = k > bias ? k - bias : 0u;
+  return rel < max_key ? rel : max_key;
+}
+
 // Bijective remap of a linear block id so that the blocks dealt to one XCD (ids congruent mod 8 under the
 // observed round-robin placement; speed only, never correctness) cover a contiguous range of work items.
 __device__ __forceinline__ int gsr_xcd_remap(int bid, int n) {

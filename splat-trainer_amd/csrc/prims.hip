@@ -130,23 +130,29 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
 }
 
 // ------------------------------------------------------------------------------------------ radix sort
-// Stable LSD radix sort, 8-bit digits, four launches per pass:
+// Stable LSD radix sort, four launches per pass:
 //   rs_hist        per-block digit histogram (LDS atomics) -> hist[digit][block];  rs_row_total: totals per digit
 //   rs_digit_scan  one block per digit: base = sum of the totals of smaller digits, then an exclusive scan of the
 //                  digit's row over blocks
 //   rs_scatter     per-round (256 elements) ballot-match ranking inside each wave, wave counts through LDS;
 //                  elements keep their input order inside every digit bucket (stable).  Up to two value arrays.
+// Digits are 8 bits wide, or 9 (512 bins, two per thread) when that saves a pass: the depth keys of a frame span
+// bits(far) - bits(near), 27 bits for near 0.1 / far 100 -- three 9-bit passes instead of four 8-bit ones.
 constexpr int RS_THREADS = 256;
-constexpr int RS_BINS = 256;
+constexpr int RS_MAX_BINS = 512;
 
 inline int rs_rounds_for(int64_t n) { return n < (4ll << 20) ? 4 : 16; }     // 1024 or 4096 pairs per block
+inline int rs_digit_bits(int bits) { return (bits + 8) / 9 < (bits + 7) / 8 ? 9 : 8; }
 
+template <int BITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
                                                              uint32_t mask, int rounds, uint32_t* __restrict__ hist,
                                                              uint32_t num_blocks, const uint32_t* __restrict__ n_dev) {
-  __shared__ uint32_t s_hist[RS_BINS];
+  constexpr int BINS = 1 << BITS, PER = BINS / RS_THREADS;
+  __shared__ uint32_t s_hist[BINS];
   if (n_dev) n = min(n, *n_dev);              // n is a capacity: the element count is still on the device
-  s_hist[threadIdx.x] = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) s_hist[threadIdx.x + k * RS_THREADS] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * (uint32_t)(rounds * RS_THREADS);
   for (int r = 0; r < rounds; ++r) {
@@ -154,7 +160,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
     if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & mask], 1u);
   }
   __syncthreads();
-  hist[threadIdx.x * num_blocks + blockIdx.x] = s_hist[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t d = threadIdx.x + k * RS_THREADS;
+    hist[(size_t)d * num_blocks + blockIdx.x] = s_hist[d];
+  }
 }
 
 // one block per digit: total count of the digit over all blocks (global atomics on 256 hot words measured 3x slower)
@@ -177,8 +187,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(const uint32_
   __shared__ uint32_t s_carry;
   const uint32_t d = blockIdx.x;
   const int lane = gsr_lane(), wave = threadIdx.x >> 6;
-  // base of this digit = total count of all smaller digits
-  uint32_t t = (threadIdx.x < d) ? digit_total[threadIdx.x] : 0u;
+  // base of this digit = total count of all smaller digits (the grid has one block per digit: 256 or 512)
+  uint32_t t = 0;
+  for (uint32_t j = threadIdx.x; j < d; j += RS_THREADS) t += digit_total[j];
   t = gsr_wave_sum_u32(t);
   if (lane == 0) s_wave[wave] = t;
   __syncthreads();
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(const uint32_
 // image (ballot-match ranks inside each wave, wave counts through LDS, running per-digit counts across rounds), then
 // written out in image order: consecutive threads write consecutive addresses inside each digit run, so the global
 // stores are coalesced segments instead of 4-byte singles.
-template <bool TWO, int ROUNDS>
+template <bool TWO, int ROUNDS, int BITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,   // null -> iota
                                                                 const uint32_t* __restrict__ vals2_in,
@@ -221,29 +232,40 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ offsets,
                                                                 uint32_t num_blocks, const uint32_t* __restrict__ n_dev) {
   constexpr int TILE = ROUNDS * RS_THREADS;
+  constexpr int BINS = 1 << BITS, PER = BINS / RS_THREADS;     // thread t owns the consecutive digits PER t .. PER t + PER - 1
   if (n_dev) n = min(n, *n_dev);
   if (blockIdx.x * (uint32_t)TILE >= n) return;   // uniform over the block; its histogram row is all zeros
-  __shared__ uint32_t s_start[RS_BINS];       // first image slot of each digit
-  __shared__ uint32_t s_goff[RS_BINS];        // global slot of the digit's first element of this block
-  __shared__ uint32_t s_run[RS_BINS];         // elements of the digit placed by earlier rounds
-  __shared__ uint32_t s_wcnt[4][RS_BINS];     // per-wave digit counts of the current round
+  __shared__ uint32_t s_start[BINS];          // first image slot of each digit
+  __shared__ uint32_t s_goff[BINS];           // global slot of the digit's first element of this block
+  __shared__ uint32_t s_run[BINS];            // elements of the digit placed by earlier rounds
+  __shared__ uint32_t s_wcnt[4][BINS];        // per-wave digit counts of the current round
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_key[TILE];
   __shared__ uint32_t s_val[TILE];
   __shared__ uint32_t s_val2[TWO ? TILE : 1];
   const int lane = gsr_lane(), wave = threadIdx.x >> 6;
   {
-    const uint32_t c = counts[threadIdx.x * num_blocks + blockIdx.x];
-    s_goff[threadIdx.x] = offsets[threadIdx.x * num_blocks + blockIdx.x];
-    s_run[threadIdx.x] = 0;
-    const uint32_t incl = gsr_wave_scan_incl_u32(c);
+    uint32_t c[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t d = PER * threadIdx.x + k;
+      c[k] = counts[(size_t)d * num_blocks + blockIdx.x];
+      s_goff[d] = offsets[(size_t)d * num_blocks + blockIdx.x];
+      s_run[d] = 0;
+      mine += c[k];
+    }
+    const uint32_t incl = gsr_wave_scan_incl_u32(mine);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    uint32_t wbase = 0;
+    uint32_t at = incl - mine;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-      if (w < wave) wbase += s_wave[w];
-    s_start[threadIdx.x] = wbase + incl - c;
+      if (w < wave) at += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      s_start[PER * threadIdx.x + k] = at;
+      at += c[k];
+    }
   }
   const uint32_t base = blockIdx.x * (uint32_t)TILE;
   const uint32_t block_n = min((uint32_t)TILE, n - base);
@@ -251,7 +273,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     const uint32_t round_base = base + r * RS_THREADS;
     if (round_base >= n) break;                               // uniform over the block
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s_wcnt[w][threadIdx.x] = 0;
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int k = 0; k < PER; ++k) s_wcnt[w][threadIdx.x + k * RS_THREADS] = 0;
     __syncthreads();
     const uint32_t idx = round_base + threadIdx.x;
     const bool valid = idx < n;
@@ -264,7 +288,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     }
     uint64_t peers = __ballot(valid);                          // lanes of this wave holding the same digit
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       uint64_t bit = __ballot((digit >> b) & 1u);
       peers &= ((digit >> b) & 1u) ? bit : ~bit;
     }
@@ -281,7 +305,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
       if (TWO) s_val2[slot] = val2;
     }
     __syncthreads();
-    s_run[threadIdx.x] += s_wcnt[0][threadIdx.x] + s_wcnt[1][threadIdx.x] + s_wcnt[2][threadIdx.x] + s_wcnt[3][threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t d = threadIdx.x + k * RS_THREADS;
+      s_run[d] += s_wcnt[0][d] + s_wcnt[1][d] + s_wcnt[2][d] + s_wcnt[3][d];
+    }
   }
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < block_n; e += RS_THREADS) {
@@ -295,11 +323,66 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
 }
 
 size_t sort_ws_bytes(int64_t n) {
-  if (n <= 0) return 1024 * 5 + 256;
+  if (n <= 0) return 2048 * 5 + 256;
   const uint64_t tile = (uint64_t)rs_rounds_for(n) * RS_THREADS;
   const uint64_t nb = ((uint64_t)n + tile - 1) / tile;
-  const size_t hist = ((nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
-  return 2 * hist + 5 * RS_BINS * sizeof(uint32_t) + 256;    // counts + offsets tables + digit totals
+  const size_t hist = ((nb * RS_MAX_BINS * sizeof(uint32_t) + 255) / 256) * 256;
+  return 2 * hist + 5 * RS_MAX_BINS * sizeof(uint32_t) + 256;    // counts + offsets tables + digit totals
+}
+
+template <bool TWO, int ROUNDS, int BITS>
+void rs_launch_scatter(uint32_t nb, hipStream_t stream, const uint32_t* kin, const uint32_t* vin, const uint32_t* v2in,
+                       uint32_t* kout, uint32_t* vout, uint32_t* v2out, uint32_t n, int bit, uint32_t mask,
+                       const uint32_t* hist, const uint32_t* offs, const uint32_t* n_dev) {
+  rs_scatter_kernel<TWO, ROUNDS, BITS><<<nb, RS_THREADS, 0, stream>>>(kin, vin, v2in, kout, vout, v2out, n, bit, mask, hist,
+                                                                      offs, nb, n_dev);
+}
+
+template <int BITS>
+int sort_passes(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
+                uint32_t* vals2_b, int64_t n, int vals_are_iota, int begin_bit, int end_bit, void* workspace,
+                const uint32_t* n_dev, hipStream_t stream) {
+  constexpr int BINS = 1 << BITS;
+  const bool two = vals2_a != nullptr;
+  const int rounds = rs_rounds_for(n);
+  const uint32_t tile = (uint32_t)(rounds * RS_THREADS);
+  const uint32_t nb = (uint32_t)((n + tile - 1) / tile);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
+  const size_t hist_bytes = (((size_t)nb * RS_MAX_BINS * sizeof(uint32_t) + 255) / 256) * 256;
+  uint32_t* offs = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + hist_bytes);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + 2 * hist_bytes);
+  int passes = (end_bit - begin_bit + BITS - 1) / BITS;
+  if (passes < 1) passes = 1;
+  if (passes > 5) return GSR_ERR_INVALID_ARGUMENT;
+
+  uint32_t* kin = keys_a; uint32_t* kout = keys_b;
+  const uint32_t* vin = vals_are_iota ? nullptr : vals_a; uint32_t* vout = vals_b;
+  const uint32_t* v2in = vals2_a; uint32_t* v2out = vals2_b;
+  int where = 0;
+  for (int p = 0; p < passes; ++p) {
+    const int bit = begin_bit + BITS * p;
+    int bits = end_bit - bit; if (bits > BITS) bits = BITS; if (bits < 0) bits = 0;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t* tot = totals + (size_t)p * RS_MAX_BINS;
+    rs_hist_kernel<BITS><<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, rounds, hist, nb, n_dev);
+    GSR_CHECK_LAUNCH();
+    rs_row_total_kernel<<<BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
+    GSR_CHECK_LAUNCH();
+    rs_digit_scan_kernel<<<BINS, RS_THREADS, 0, stream>>>(hist, offs, nb, tot);
+    GSR_CHECK_LAUNCH();
+    if (two) {
+      if (rounds == 4) rs_launch_scatter<true, 4, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
+      else rs_launch_scatter<true, 16, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
+    } else {
+      if (rounds == 4) rs_launch_scatter<false, 4, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
+      else rs_launch_scatter<false, 16, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
+    }
+    GSR_CHECK_LAUNCH();
+    where ^= 1;
+    if (where == 1) { kin = keys_b; vin = vals_b; v2in = vals2_b; kout = keys_a; vout = vals_a; v2out = vals2_a; }
+    else            { kin = keys_a; vin = vals_a; v2in = vals2_a; kout = keys_b; vout = vals_b; v2out = vals2_b; }
+  }
+  return where;
 }
 
 int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* keys_b, uint32_t* vals_b,
@@ -310,44 +393,11 @@ int sort_impl(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t* k
   if (n > 0 && (!keys_a || !vals_a || !keys_b || !vals_b || (two && !vals2_b))) return GSR_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < sort_ws_bytes(n) || !workspace) return GSR_ERR_WORKSPACE_TOO_SMALL;
   if (n == 0) return 0;
-  const int rounds = rs_rounds_for(n);
-  const uint32_t tile = (uint32_t)(rounds * RS_THREADS);
-  const uint32_t nb = (uint32_t)((n + tile - 1) / tile);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
-  const size_t hist_bytes = (((size_t)nb * RS_BINS * sizeof(uint32_t) + 255) / 256) * 256;
-  uint32_t* offs = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + hist_bytes);
-  uint32_t* totals = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + 2 * hist_bytes);
-  int passes = (end_bit - begin_bit + 7) / 8;
-  if (passes < 1) passes = 1;
-  if (passes > 5) return GSR_ERR_INVALID_ARGUMENT;
-
-  uint32_t* kin = keys_a; uint32_t* kout = keys_b;
-  const uint32_t* vin = vals_are_iota ? nullptr : vals_a; uint32_t* vout = vals_b;
-  const uint32_t* v2in = vals2_a; uint32_t* v2out = vals2_b;
-  int where = 0;
-  for (int p = 0; p < passes; ++p) {
-    const int bit = begin_bit + 8 * p;
-    int bits = end_bit - bit; if (bits > 8) bits = 8; if (bits < 0) bits = 0;
-    const uint32_t mask = bits >= 8 ? 0xFFu : ((1u << bits) - 1u);
-    uint32_t* tot = totals + (size_t)p * RS_BINS;
-    rs_hist_kernel<<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, rounds, hist, nb, n_dev);
-    GSR_CHECK_LAUNCH();
-    rs_row_total_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
-    GSR_CHECK_LAUNCH();
-    rs_digit_scan_kernel<<<RS_BINS, RS_THREADS, 0, stream>>>(hist, offs, nb, tot);
-    GSR_CHECK_LAUNCH();
-#define GSR_RS_SCATTER(TWO_, R_)                                                                                     \
-  rs_scatter_kernel<TWO_, R_><<<nb, RS_THREADS, 0, stream>>>(kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, \
-                                                             hist, offs, nb, n_dev)
-    if (two) { if (rounds == 4) GSR_RS_SCATTER(true, 4); else GSR_RS_SCATTER(true, 16); }
-    else     { if (rounds == 4) GSR_RS_SCATTER(false, 4); else GSR_RS_SCATTER(false, 16); }
-#undef GSR_RS_SCATTER
-    GSR_CHECK_LAUNCH();
-    where ^= 1;
-    if (where == 1) { kin = keys_b; vin = vals_b; v2in = vals2_b; kout = keys_a; vout = vals_a; v2out = vals2_a; }
-    else            { kin = keys_a; vin = vals_a; v2in = vals2_a; kout = keys_b; vout = vals_b; v2out = vals2_b; }
-  }
-  return where;
+  if (rs_digit_bits(end_bit - begin_bit) == 9)
+    return sort_passes<9>(keys_a, vals_a, vals2_a, keys_b, vals_b, vals2_b, n, vals_are_iota, begin_bit, end_bit, workspace,
+                          n_dev, stream);
+  return sort_passes<8>(keys_a, vals_a, vals2_a, keys_b, vals_b, vals2_b, n, vals_are_iota, begin_bit, end_bit, workspace,
+                        n_dev, stream);
 }
 
 }  // namespace

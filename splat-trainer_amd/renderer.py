@@ -191,11 +191,12 @@ class _ProjectFn(torch.autograd.Function):
     g2d_full = torch.empty(N, 6, dtype=torch.float32, device=dev)
     depth_full = torch.empty(N, 1, dtype=torch.float32, device=dev)
     keys_full = _u32(N, dev) if prefetch is not None else None     # the depth sort's keys, when the caller rasterizes next
+    key_range = _depth_key_range(near, far)
     _lib.check(lib.gsr_frustum_cull(_ptr(pos), N, _ptr(T), _ptr(proj), W, H, near, far, margin, _ptr(indexes_full),
                                     _ptr(count), _ptr(ws), ws_bytes, stream), "gsr_frustum_cull")
     _lib.check(lib.gsr_project_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes_full), N, _ptr(T),
                                        _ptr(proj), C.byref(params), _ptr(g2d_full), _ptr(depth_full), _ptr(count),
-                                       _ptr(keys_full), stream), "gsr_project_forward")
+                                       _ptr(keys_full), key_range[0], key_range[1], stream), "gsr_project_forward")
     wait = _start_readback(count)  # host sync #1 (K2 is already running)
     sh_job = prefetch.pop("sh", None) if prefetch is not None else None
     if sh_job is not None and N > 0:
@@ -209,7 +210,7 @@ class _ProjectFn(torch.autograd.Function):
     if prefetch is not None and M > 0:
       # the caller will rasterize next: the depth sort needs only `depth`, so it is enqueued now and runs while the host
       # works its way to render_projected (the GPU would otherwise idle behind the sync)
-      prefetch["order"] = _launch_depth_order(depth.reshape(-1), M, keys=keys_full[:M])
+      prefetch["order"] = _launch_depth_order(depth.reshape(-1), M, key_range, keys=keys_full[:M])
     ctx.save_for_backward(pos, ls, rot, al, indexes, T, proj)
     ctx.set_materialize_grads(False)       # an unused output (depth, usually) arrives as None, not as a zero-filled tensor
     ctx.params = params
@@ -272,26 +273,45 @@ class _RasterState:
   __slots__ = ("M", "O", "C", "W", "H", "params", "rec", "order", "count", "offsets", "sorted_rank",
                "sorted_inst", "tile_range", "vis_partial", "pair_vis", "final_T", "last", "median", "visibility",
                "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad",
-               "segments", "segment_buffers", "seg_pairs", "seg_min", "image")
+               "segments", "segment_buffers", "seg_pairs", "seg_min", "image", "key_range")
 
 
 def _u32(n: int, device) -> torch.Tensor:
   return torch.empty(max(n, 1), dtype=torch.int32, device=device)   # raw storage for uint32 arrays
 
 
-def _launch_depth_order(depth: torch.Tensor, M: int, keys: Optional[torch.Tensor] = None) -> torch.Tensor:
-  """depth keys + stable 32-bit radix sort of the M splats (ties keep ascending index); returns order (M,) int32.
-  ``keys``: the keys when K2 has already written them (consumed as sort scratch)."""
+_KEY_RANGES = {}
+
+
+def _depth_key_range(near: float, far: float):
+  """(bias, max_key, significant bits) of the depth sort keys of a camera: keys are taken relative to the near plane
+  (binning.hip: gsr_depth_key_range), so the stable radix sort only has to cover bits(far) - bits(near)."""
+  key = (float(near), float(far))
+  hit = _KEY_RANGES.get(key)
+  if hit is None:
+    bias, top = C.c_uint32(0), C.c_uint32(0)
+    _lib.check(_lib.load().gsr_depth_key_range(key[0], key[1], C.byref(bias), C.byref(top)), "gsr_depth_key_range")
+    hit = _KEY_RANGES[key] = (bias.value, top.value, max(1, int(top.value).bit_length()))
+    if len(_KEY_RANGES) > 4096:
+      _KEY_RANGES.clear()
+  return hit
+
+
+def _launch_depth_order(depth: torch.Tensor, M: int, key_range, keys: Optional[torch.Tensor] = None) -> torch.Tensor:
+  """depth keys + stable radix sort of the M splats over the keys' significant bits (ties keep ascending index); returns
+  order (M,) int32.  ``key_range`` = _depth_key_range(near, far); ``keys``: the keys when K2 has already written them
+  (consumed as sort scratch)."""
   lib = _lib.load()
   dev = depth.device
   stream = _stream()
+  bias, max_key, key_bits = key_range
   keys_a = keys if keys is not None else _u32(M, dev)
   keys_b, vals_a, vals_b = _u32(M, dev), _u32(M, dev), _u32(M, dev)
   sort_bytes = lib.gsr_sort_workspace_bytes(M)
   sort_ws = torch.empty(sort_bytes, dtype=torch.uint8, device=dev)
   if keys is None:
-    _lib.check(lib.gsr_depth_keys(_ptr(depth), M, _ptr(keys_a), stream), "gsr_depth_keys")
-  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, 32,
+    _lib.check(lib.gsr_depth_keys(_ptr(depth), M, bias, max_key, _ptr(keys_a), stream), "gsr_depth_keys")
+  where = _lib.check(lib.gsr_sort_pairs_u32(_ptr(keys_a), _ptr(vals_a), _ptr(keys_b), _ptr(vals_b), M, 1, 0, key_bits,
                                             _ptr(sort_ws), sort_bytes, None, stream), "gsr_sort_pairs_u32(depth)")
   return vals_b if where == 1 else vals_a
 
@@ -367,7 +387,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   st.screen_scale = torch.empty(M, 2, dtype=torch.float32, device=dev)   # written for every splat by K4
 
   # depth order of the M splats (stable: ties keep ascending index); project_to_image may already have enqueued it
-  st.order = order if order is not None else _launch_depth_order(depth, M)
+  st.order = order if order is not None else _launch_depth_order(depth, M, st.key_range)
 
   # per-splat tile counts + depth-ordered records
   st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
@@ -532,6 +552,7 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
   st.segments = None
   st.segment_buffers = None
   st.seg_pairs, st.seg_min = int(config.segment_pairs), int(config.segment_min_pairs)
+  st.key_range = _depth_key_range(float(camera_params.near_plane), float(camera_params.far_plane))
   st.needs_grad = torch.is_grad_enabled() and (gaussians2d.requires_grad or features.requires_grad)
   order = None
   if _depth_order is not None and _depth_order[1] is depth and _depth_order[2] == depth._version:

@@ -127,6 +127,49 @@ def test_radix_sort_with_count_on_the_device(n, capacity):
   assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,bits", [(257, 9), (1025, 17), (70_001, 18), (500_000, 27), (4_500_001, 27), (300_000, 26),
+                                    (123_457, 25), (5_000_000, 9)])
+def test_radix_sort_nine_bit_digits(n, bits):
+  """Key widths where 9-bit digits (512 bins) save a pass over 8-bit ones: 9, 17-18 and 25-27 bits (the depth keys of a
+  frame span 27 bits for near 0.1 / far 100).  Same stable result as numpy; bits above ``bits`` are ignored."""
+  rng = np.random.default_rng(n + bits)
+  keys = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+  keys[rng.integers(0, n, size=n // 4)] = keys[0]
+  k, v = _sort(keys, 0, bits)
+  low = keys & np.uint32((1 << bits) - 1)
+  order = np.argsort(low, kind="stable")
+  assert np.array_equal(k, keys[order])
+  assert np.array_equal(v, order.astype(np.uint32))
+
+
+def test_depth_keys_relative_to_the_near_plane_sort_like_the_depths():
+  """gsr_depth_key_range + gsr_depth_keys: keys start at 0 for the near plane, are monotone in depth, need 27 bits for
+  0.1 .. 100, clamp outside the range, and the stable sort over just those bits orders the depths (ties by index)."""
+  lib = _lib.load()
+  bias, top = C.c_uint32(0), C.c_uint32(0)
+  _lib.check(lib.gsr_depth_key_range(0.1, 100.0, C.byref(bias), C.byref(top)), "range")
+  assert int(top.value).bit_length() == 27
+  n = 400_000
+  rng = np.random.default_rng(0)
+  depth = np.exp(rng.uniform(np.log(0.1000001), np.log(99.9999), size=n)).astype(np.float32)
+  depth[rng.integers(0, n, size=n // 5)] = depth[7]                          # ties
+  depth[:4] = [0.05, 1e-3, 150.0, 1e9]                                       # outside [near, far]: clamped, never wrapped
+  d = torch.from_numpy(depth).cuda()
+  keys = torch.empty(n, dtype=torch.int32, device="cuda")
+  _lib.check(lib.gsr_depth_keys(_ptr(d), n, bias.value, top.value, _ptr(keys), _stream()), "keys")
+  k = keys.cpu().numpy().view(np.uint32)
+  assert k[0] == 0 and k[1] == 0 and k[2] == top.value and k[3] == top.value and k.max() <= top.value
+  inside = np.arange(4, n)
+  o = np.argsort(depth[inside], kind="stable")
+  assert np.all(np.diff(k[inside][o].astype(np.int64)) >= 0)                # monotone
+  assert np.array_equal(np.argsort(k[inside], kind="stable"), o)             # exactly the depths' order, ties by index
+  sk, sv = _sort(k, 0, 27)
+  assert np.array_equal(sv, np.argsort(k, kind="stable").astype(np.uint32))
+  # an unbounded range falls back to plain 32-bit keys
+  _lib.check(lib.gsr_depth_key_range(0.0, 100.0, C.byref(bias), C.byref(top)), "range")
+  assert bias.value == 0 and top.value == 0xFFFFFFFF
+
+
 @pytest.mark.parametrize("bits", [1, 7, 8, 13, 15, 20])
 def test_radix_sort_partial_bits_keeps_input_order(bits):
   n = 500_003

@@ -273,6 +273,10 @@ int gsr_opt_point_weights(const int64_t* indexes, const float* visibility, int64
 int gsr_opt_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* indexes,
                  const float* row_scale, const float* basis, int64_t M, int32_t D, int32_t type, int32_t algo, float lr,
                  float beta1, float beta2, float eps, float grad_clip, void* stream);
+/* basis_out [M,3,3] row-major = R(normalize(rotation[i])) * diag(max(exp(log_scaling[i]), eps)), i = indexes[m] (NULL:
+ * i = m): the frame local_vector groups step in (gaussians/split.py:16-20, mlp_scene.py:219-225). */
+int gsr_point_basis(const float* log_scaling, const float* rotation_xyzw, const int64_t* indexes, int64_t M, float eps,
+                    float* basis_out, void* stream);
 
 /* ---- densify / prune support next to the path ------------------------------------------
  *      deterministic top-n mask replacing take_n = argsort(t)[:n] -> mask (splat_trainer/controller/target_controller.py:

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "gsr_compact_workspace_bytes": (_sz, [_i64]),
     "gsr_compact_offsets": (C.c_int, [_p, _i64, _p, _p, _p, _sz, _p]),
     "gsr_compact_columns": (C.c_int, [_p, _i64, _p, _i64, _i64, C.POINTER(GsrColumnC), _i32, _p]),
+    "gsr_point_basis": (C.c_int, [_p, _p, _p, _i64, _f, _p, _p]),
     "gsr_dp_pack": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "gsr_dp_replay": (C.c_int, [_p, _i64, _p, _i32, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p]),

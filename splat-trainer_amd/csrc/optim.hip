@@ -171,6 +171,27 @@ __global__ __launch_bounds__(256) void opt_step_wide_kernel(float* __restrict__ 
   if (TYPE == OPT_VECTOR && sub == 0) exp_avg_sq[idx] = v_row;
 }
 
+// basis[m] = R(normalize(q[i])) * diag(max(exp(log_scaling[i]), eps)), i = indexes[m] (or m): the splat's own frame
+// the local_vector groups step in (splat_trainer/gaussians/split.py:16-20, mlp_scene.py:219-225) -- one launch instead
+// of the dozen elementwise torch kernels of the expression, which at 3 M rows cost more than the optimizer step itself.
+__global__ __launch_bounds__(256) void point_basis_kernel(const float* __restrict__ log_scaling,
+                                                          const float* __restrict__ rotation,
+                                                          const int64_t* __restrict__ indexes, int64_t M, float eps,
+                                                          float* __restrict__ basis) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int64_t i = indexes ? indexes[m] : m;
+  const float4 qv = *reinterpret_cast<const float4*>(rotation + 4 * i);
+  const float n = fmaxf(sqrtf(qv.x * qv.x + qv.y * qv.y + qv.z * qv.z + qv.w * qv.w), 1e-12f);   // F.normalize
+  const float x = qv.x / n, y = qv.y / n, z = qv.z / n, w = qv.w / n;
+  const float s0 = fmaxf(expf(log_scaling[3 * i]), eps), s1 = fmaxf(expf(log_scaling[3 * i + 1]), eps),
+              s2 = fmaxf(expf(log_scaling[3 * i + 2]), eps);
+  float* b = basis + 9 * m;
+  b[0] = (1.f - 2.f * (y * y + z * z)) * s0; b[1] = (2.f * (x * y - w * z)) * s1; b[2] = (2.f * (x * z + w * y)) * s2;
+  b[3] = (2.f * (x * y + w * z)) * s0; b[4] = (1.f - 2.f * (x * x + z * z)) * s1; b[5] = (2.f * (y * z - w * x)) * s2;
+  b[6] = (2.f * (x * z - w * y)) * s0; b[7] = (2.f * (y * z + w * x)) * s1; b[8] = (1.f - 2.f * (x * x + y * y)) * s2;
+}
+
 }  // namespace
 
 extern "C" {
@@ -234,6 +255,17 @@ int gsr_opt_step(float* param, const float* grad, float* exp_avg, float* exp_avg
       opt_step_wide_kernel<OPT_VECTOR><<<wb, 256, 0, stream>>>(param, grad, exp_avg, exp_avg_sq, indexes, rs, M, D, a);
   }
 #undef GSR_OPT_NARROW
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_point_basis(const float* log_scaling, const float* rotation_xyzw, const int64_t* indexes, int64_t M, float eps,
+                    float* basis_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!log_scaling || !rotation_xyzw || !basis_out) return GSR_ERR_INVALID_ARGUMENT;
+  point_basis_kernel<<<(unsigned)((M + 255) / 256), 256, 0, stream>>>(log_scaling, rotation_xyzw, indexes, M, eps, basis_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

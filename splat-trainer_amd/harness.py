@@ -28,7 +28,7 @@ import torch.nn.functional as F
 
 from .controller_math import PointState, find_split_prune_indexes
 from .data_types import CameraParams, Gaussians3D, RasterConfig
-from .optim import ParameterClass, VisibilityAwareLaProp
+from .optim import ParameterClass, VisibilityAwareLaProp, point_basis_rows
 from .tensor_rows import TensorRows
 from .loss import clamped_mse_loss
 from .renderer import GradOut, render_gaussians
@@ -123,7 +123,10 @@ class MiniTrainer:
     """mlp_scene.py:214-239."""
     pts = self.points
     vis_idx = pts.visible.nonzero().squeeze(1)
-    basis = point_basis(pts.log_scaling.detach()[vis_idx], pts.rotation.detach()[vis_idx]).contiguous()
+    if pts.log_scaling.is_cuda:          # one launch instead of the expression's dozen (0.1 instead of 1 ms at 3 M rows)
+      basis = point_basis_rows(pts.log_scaling, pts.rotation, vis_idx)
+    else:
+      basis = point_basis(pts.log_scaling.detach()[vis_idx], pts.rotation.detach()[vis_idx]).contiguous()
     if pts.optimizer.visibility_aware:
       pts.step(visibility=pts.visible[vis_idx], indexes=vis_idx, basis=basis)
     else:

@@ -57,6 +57,22 @@ def _ptr(t: Optional[torch.Tensor]):
   return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def point_basis_rows(log_scaling: torch.Tensor, rotation: torch.Tensor, indexes: Optional[torch.Tensor] = None,
+                     eps: float = 1e-4) -> torch.Tensor:
+  """``point_basis(log_scaling[indexes], rotation[indexes])`` (splat_trainer/gaussians/split.py:16-20) as one launch:
+  (M,3,3) = R(normalised xyzw quaternion) with columns scaled by ``clamp_min(exp(log_scaling), eps)`` -- the ``basis``
+  argument of ``ParameterClass.step`` (mlp_scene.py:219-230).  ``indexes`` None: all rows."""
+  ls = log_scaling.detach().to(torch.float32).contiguous()
+  rot = rotation.detach().to(torch.float32).contiguous()
+  if not (ls.is_cuda and rot.is_cuda):
+    raise _lib.GsplatHipError("point_basis_rows runs only on a HIP device; there is no CPU fallback")
+  M = int(indexes.shape[0]) if indexes is not None else int(ls.shape[0])
+  out = torch.empty(M, 3, 3, dtype=torch.float32, device=ls.device)
+  _lib.check(_lib.load().gsr_point_basis(_ptr(ls), _ptr(rot), _ptr(indexes.contiguous()) if indexes is not None else None,
+                                         M, float(eps), _ptr(out), _lib.current_stream_ptr()), "gsr_point_basis")
+  return out
+
+
 class ParameterClass:
   """Named per-point tensors with one parameter group each, optimizer state stored as same-length columns so that
   masking (``pc[keep_mask]``) and ``append_tensors`` carry it along (mlp_scene.py:301-310)."""

@@ -115,3 +115,22 @@ def test_step_argument_errors():
     pc.step(indexes=idx, visibility=torch.ones(8, device="cuda"))                     # basis missing
   with pytest.raises(ValueError):
     pc.step(indexes=idx.int(), visibility=torch.ones(8, device="cuda"))
+
+
+def test_point_basis_rows_matches_the_torch_expression():
+  """optim.point_basis_rows (one launch) against harness.point_basis, the restated split.py:16-20 expression."""
+  from splat_trainer_amd.harness import point_basis
+  from splat_trainer_amd.optim import point_basis_rows
+  gen = torch.Generator().manual_seed(4)
+  n = 5000
+  ls = (torch.randn(n, 3, generator=gen) * 2 - 3).cuda()
+  ls[:5] = -20.0                                             # exp below eps: the clamp decides
+  rot = torch.randn(n, 4, generator=gen).cuda()              # deliberately not normalised
+  idx = torch.randperm(n, generator=gen)[:1234].sort().values.cuda()
+  for rows in (None, idx):
+    got = point_basis_rows(ls, rot, rows)
+    want = point_basis(ls if rows is None else ls[rows], rot if rows is None else rot[rows])
+    assert got.shape == want.shape
+    # entries such as 1 - 2 (y^2 + z^2) cancel: absolute tolerance relative to the row's own scale
+    err = (got - want).abs() / want.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+    assert err.max() < 2e-6, float(err.max())

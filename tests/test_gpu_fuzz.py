@@ -68,3 +68,31 @@ def test_random_scene_matches_oracle(seed):
       continue
     worst, frac = observe(f"fuzz seed {seed}", k, hip[k], orc[k], tol)
     assert frac == 0 and worst < tol, (seed, k, frac, worst)
+
+
+FLIP_SEEDS = (46, 73, 88, 95, 96, 161, 174, 206, 222)
+
+
+@pytest.mark.parametrize("seed", FLIP_SEEDS)
+def test_random_scenes_with_a_boundary_flip_stay_isolated(seed):
+  """A one-off sweep over 200 further seeds (32..231) found these nine (4.5 %) with entries above 2e-4: a pixel within
+  fp32 rounding of a discrete contribute / skip boundary (q = 9, alpha = 1/255, T = 1e-4) takes the other branch than the
+  fp64 oracle and moves that pixel -- and the sums of the one or two splats involved -- by one minimal contribution.
+  The round-1 build shows the same nine seeds with the same figures, so this is arithmetic, not a defect of a later
+  change.  Kept as a regression net with the observed sizes x 2: at most 0.4 % of a tensor's entries (or 3 of them, for
+  the small per-point tensors) may exceed 2e-4, by at most 1e-2 of the tensor's largest magnitude, and the visible set
+  must be identical."""
+  g, cam, cfg = random_case(seed)
+  hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+  orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+  assert len(set(hip["idx"].tolist()) ^ set(orc["idx"].tolist())) == 0
+  flipped = False
+  for k in ("image", "final_T", "visibility", "prune_cost", "split_score", "screen_scale", "depth", "d_position",
+            "d_log_scaling", "d_rotation", "d_alpha_logit", "d_feature"):
+    if orc[k].abs().max() == 0:
+      assert hip[k].abs().max() == 0, (seed, k)
+      continue
+    worst, frac = observe(f"fuzz flip seed {seed}", k, hip[k], orc[k], 2e-4)
+    assert frac * hip[k].numel() <= max(3.0, 4e-3 * hip[k].numel()) + 0.5 and worst < 1e-2, (seed, k, frac, worst)
+    flipped |= frac > 0
+  assert flipped, "this seed no longer shows a flip: move it to the clean sweep"

@@ -293,6 +293,16 @@ def main():
     ref.run(batch, render_backward)
     check = max(float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(got, ref.grads.values()))
     bucket.attach()
+    # controller statistics: one exchanged batch against the reference's own loop over ALL cameras on this rank
+    exchanged, sequential = PointState.new_zeros(N, dev), PointState.new_zeros(N, dev)
+    dp.run(batch, render_backward, point_state=exchanged)
+    solo = CameraShardedStep(params, 1, 0, with_stats=False)
+    solo.run(batch, render_backward, point_state=sequential)
+    bucket.attach()
+    stats_check = {f: bool(torch.equal(getattr(exchanged, f), getattr(sequential, f)))
+                   for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view")}
+    stats_check["visibility_rel_err"] = float((exchanged.visibility - sequential.visibility).norm() /
+                                              sequential.visibility.norm().clamp_min(1e-30))
 
   r = last["r"]
   M, O = int(r.points.idx.shape[0]), int(r.num_overlaps)
@@ -367,6 +377,7 @@ def main():
     }
     if check is not None:
       out["config"]["collective_check_rel_err"] = check
+      out["config"]["statistics_check_bit_identical"] = stats_check
     if world == 1 and not args.no_cpu_baseline:
       try:
         out["cpu_baseline"] = cpu_baseline(g, cams[0], cfg)

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
   if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
   const int64_t i = idx[m];
   float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
-  const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+  // explicit fma chains wherever the colour is formed: both instantiations (JAC or not) must round identically
+  const float inv = 1.f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
   const float x = dx * inv, y = dy * inv, z = dz * inv;
   float Y[K];
   gsr_sh_basis<K>(x, y, z, Y);
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      acc += w[k] * Y[k];
+      acc = fmaf(w[k], Y[k], acc);
       if (JAC && k > 0) { gx += w[k] * dYx[k]; gy += w[k] * dYy[k]; gz += w[k] * dYz[k]; }
     }
     out[3 * m + ch] = acc;

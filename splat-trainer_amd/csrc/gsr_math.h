@@ -237,8 +237,14 @@ GSR_HD GsrProjectGrad gsr_project_one_bwd(const GsrCam& c, const GsrRasterParams
 #define GSR_SH_C0 0.28209479177387814f
 #define GSR_SH_C1 0.4886025119029199f
 
+// Every product and sum below is rounded on its own (no fma contraction): the forward kernel exists in several
+// instantiations (with / without the Jacobian the backward pass saves) that must return bit-identical colours -- a
+// data-parallel run evaluates the colours without it, a single-GPU run with it, and both must see the same image.
 template <int K>
 GSR_HD void gsr_sh_basis(float x, float y, float z, float* Y) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   Y[0] = GSR_SH_C0;
   if (K > 1) {
     Y[1] = -GSR_SH_C1 * y; Y[2] = GSR_SH_C1 * z; Y[3] = -GSR_SH_C1 * x;

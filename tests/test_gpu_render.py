@@ -513,3 +513,48 @@ def test_overlap_count_overflow_is_reported_not_wrapped():
   with pytest.raises(sta.GsplatHipError, match="2\\^31"):
     sta.render_projected(torch.arange(n, device="cuda"), g2d, torch.rand(n, 3, device="cuda"),
                          torch.rand(n, 1, device="cuda") + 1, cam, sta.RasterConfig())
+
+
+def test_image_is_bit_identical_in_every_mode_of_the_same_frame():
+  """The forward kernels exist in several instantiations -- SH colours with / without the Jacobian saved for backward,
+  composite with / without per-pair visibility and median depth -- chosen by how the caller will use the frame
+  (plain autograd, fused accumulation, data-parallel factor collection, evaluation).  They must all return the same
+  bits: a data-parallel run and a single-GPU run then see the same image, hence the same controller scores and
+  densification masks."""
+  from splat_trainer_amd import renderer
+  from splat_trainer_amd.sh import ShFactorCollector
+  g, cams = synthetic.scene_b(30_000, 320, 240, sh_degree=3, seed=5, num_cameras=2, radius=1.6)
+  cam = cams[1].to("cuda")
+  params = [t.clone().cuda().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+  scene = sta.Gaussians3D(position=params[0], rotation=params[2], log_scaling=params[1], alpha_logit=params[3], feature=params[4])
+  target = torch.full((240, 320, 3), 0.5, device="cuda")
+  grads = [torch.zeros_like(p) for p in params]
+
+  def train(mode):
+    for t in grads:
+      t.zero_()
+    with torch.enable_grad():
+      if mode == "factor":
+        go = renderer.GradOut(position=grads[0], log_scaling=grads[1], rotation=grads[2], alpha_logit=grads[3])
+        r = sta.render_gaussians(scene, cam, CFG, use_sh=True, grad_out=go, sh_collector=ShFactorCollector())
+      elif mode == "fused":
+        go = renderer.GradOut(position=grads[0], log_scaling=grads[1], rotation=grads[2], alpha_logit=grads[3],
+                              feature=grads[4], feature_uninitialized=True)
+        r = sta.render_gaussians(scene, cam, CFG, use_sh=True, grad_out=go)
+      else:
+        r = sta.render_gaussians(scene, cam, CFG, use_sh=True, render_median_depth=(mode == "median"))
+      sta.clamped_mse_loss(r.image, target).backward()
+    for p in params:
+      p.grad = None
+    return r.image.detach().clone(), r.points.split_score.clone(), r.points.prune_cost.clone(), r.points.visibility.clone()
+
+  base = train("plain")
+  for mode in ("fused", "factor", "median"):
+    got = train(mode)
+    for name, a, b in zip(("image", "split_score", "prune_cost", "visibility"), got, base):
+      assert torch.equal(a, b), (mode, name, float((a - b).abs().max()))
+  with torch.no_grad():
+    for cfg in (CFG, sta.RasterConfig(compute_visibility=False, compute_point_heuristic=False)):
+      for median in (False, True):
+        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, render_median_depth=median)
+        assert torch.equal(r.image, base[0]), (cfg.compute_visibility, median, float((r.image - base[0]).abs().max()))

@@ -398,7 +398,11 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   # Its size depends on the pair count, which is only guessed at this point (see below); a frame without a guess, or
   # one that outgrows it, pays a second fill.
   guesses = _TLS.__dict__.setdefault("overlap_guess", {})
-  guess = guesses.get(dev.index, 0) if SPECULATE else 0
+  raw_guess = guesses.get(dev.index, 0) if SPECULATE else 0
+  # the capacity moves in steps of 1/16 of its power of two: while the (slowly decaying) guess stays inside a step the
+  # O-sized buffers keep their sizes from frame to frame and the caching allocator hands the same blocks back
+  step = 1 << max(raw_guess.bit_length() - 5, 0)
+  guess = min((raw_guess + step - 1) // step * step, 0x7fffffff) if raw_guess > 0 else 0
   fixed_zeros = 2 * M + 2 * num_tiles + 4                        # ... + capacity floats of per-pair visibility
 
   def zero_block(capacity):
@@ -474,7 +478,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   if overflow or O < 0:          # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
     raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
   st.O = O
-  guesses[dev.index] = min(max(O + O // 4 + 4096, guess - guess // 64), 0x7fffffff)   # grows at once, decays slowly
+  guesses[dev.index] = min(max(O + O // 4 + 4096, raw_guess - raw_guess // 64), 0x7fffffff)   # grows at once, decays slowly
   if O == 0:
     st.segments, st.segment_buffers = None, None
     heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))

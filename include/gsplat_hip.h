@@ -59,10 +59,12 @@ typedef struct GsrRasterParamsC {
  * wave).  All pointers are device buffers owned by the caller; tile_seg / seg_desc / seg_total are filled by
  * gsr_segment_plan, the seg_* pixel buffers are scratch written by the forward pass and read by the backward pass. */
 typedef struct GsrSegmentsC {
-  const uint32_t* tile_seg;   /* [num_tiles,2]: first segment, number of segments (0 = light tile) */
+  const uint32_t* tile_seg;   /* [num_tiles,2]: first segment, number of segments (0 = light tile); followed by
+                                 [heavy_capacity]: the segments of heavy tiles, listed compactly by the plan */
   const uint32_t* seg_desc;   /* [capacity,4]: tile, list start, list end, index within the tile */
-  const uint32_t* seg_total;  /* device word: segments of this frame (<= capacity) */
+  const uint32_t* seg_total;  /* two device words: segments of this frame (<= capacity), of them in heavy tiles */
   int64_t capacity;           /* from gsr_segment_capacity */
+  int64_t heavy_capacity;     /* from gsr_segment_heavy_capacity (<= capacity) */
   float* seg_P;               /* [capacity,256] */
   float* seg_TC;              /* [capacity,256,4], 16-byte aligned: (T, c0, c1, c2) per pixel slot */
   int32_t* seg_last;          /* [capacity,256] */
@@ -196,11 +198,14 @@ int gsr_segment_thresholds(int32_t seg_pairs_cfg, int32_t heavy_min_cfg, int64_t
                            int32_t* seg_pairs_out, int32_t* heavy_min_out);
 int64_t gsr_segment_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cfg, int32_t heavy_min_cfg, int32_t num_tiles,
                              int32_t needs_grad);
-/* tile_seg_out [num_tiles,2], seg_desc_out [capacity,4], seg_total_out [1] (see GsrSegmentsC); seg_total_out must be
- * ZERO on entry (tiles reserve their segment slots with an integer atomic on it). */
+/* ... and on the number of those that belong to heavy tiles (the forward passes A and C launch one block each). */
+int64_t gsr_segment_heavy_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
+                                   int32_t num_tiles, int32_t needs_grad);
+/* tile_seg_out [2 num_tiles + heavy_capacity], seg_desc_out [capacity,4], seg_total_out [2] (see GsrSegmentsC);
+ * seg_total_out must be ZERO on entry (tiles reserve their slots with integer atomics on it). */
 int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
-                     int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, uint32_t* tile_seg_out,
-                     uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream);
+                     int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, int64_t heavy_capacity,
+                     uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream);
 
 /* ---- K6 alpha-composite forward ------------------------------------------------------------------------- */
 /* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;

@@ -25,7 +25,7 @@ class GsrRasterParamsC(C.Structure):
 
 class GsrSegmentsC(C.Structure):
   _fields_ = [("tile_seg", C.c_void_p), ("seg_desc", C.c_void_p), ("seg_total", C.c_void_p), ("capacity", C.c_int64),
-              ("seg_P", C.c_void_p), ("seg_TC", C.c_void_p), ("seg_last", C.c_void_p),
+              ("heavy_capacity", C.c_int64), ("seg_P", C.c_void_p), ("seg_TC", C.c_void_p), ("seg_last", C.c_void_p),
               ("seg_median", C.c_void_p)]
 
 
@@ -75,7 +75,8 @@ PROTOTYPES = {
     "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "gsr_segment_thresholds": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _p, _p]),
     "gsr_segment_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
-    "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _i64, _p, _p, _p, _p]),
+    "gsr_segment_heavy_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
+    "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p]),
     "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _ps, _p]),
     "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _ps, _p]),
     "gsr_opt_point_weights": (C.c_int, [_p, _p, _i64, _p, _p, _f, _f, _f, _f, _i32, _p, _p]),

@@ -257,10 +257,13 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
                                                            float* __restrict__ vis_partial,
                                                            float* __restrict__ pair_vis, SegDev seg) {
   if ((int)blockIdx.x >= num_tiles) {                                // extra blocks: pass A of the heavy tiles' segments
-    const uint32_t sidx = blockIdx.x - (uint32_t)num_tiles;
-    if (sidx < seg.seg_total[0]) {
-      const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
-      if (d[1] < d[2] && (seg.tile_seg[2 * d[0] + 1] & GSR_SEG_HEAVY)) seg_alpha_pass<C>(sidx, rec, sorted_rank, tiles_x, rp, seg);
+    const uint32_t h = blockIdx.x - (uint32_t)num_tiles;             // index into the plan's compact list of them
+    if (h < seg.seg_total[1]) {
+      const uint32_t sidx = (seg.tile_seg + 2 * (size_t)num_tiles)[h];
+      if (sidx != 0xFFFFFFFFu) {
+        const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
+        if (d[1] < d[2]) seg_alpha_pass<C>(sidx, rec, sorted_rank, tiles_x, rp, seg);
+      }
     }
     return;
   }
@@ -323,14 +326,14 @@ __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restri
                                                            const uint32_t* __restrict__ sorted_rank,
                                                            const uint32_t* __restrict__ sorted_inst,
                                                            const uint32_t* __restrict__ tile_range, int W, int H,
-                                                           int tiles_x, GsrRasterParams rp,
+                                                           int tiles_x, int num_tiles, GsrRasterParams rp,
                                                            float* __restrict__ vis_partial,
                                                            float* __restrict__ pair_vis, SegDev seg) {
-  const uint32_t sidx = blockIdx.x;
-  if (sidx >= seg.seg_total[0]) return;
+  if (blockIdx.x >= seg.seg_total[1]) return;                         // one block per segment of a HEAVY tile
+  const uint32_t sidx = (seg.tile_seg + 2 * (size_t)num_tiles)[blockIdx.x];
+  if (sidx == 0xFFFFFFFFu) return;
   const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
   const int tile = (int)d[0];
-  if (!(seg.tile_seg[2 * tile + 1] & GSR_SEG_HEAVY)) return;          // checkpointed by the one-wave walk instead
   const uint32_t begin = d[1], end = d[2];
   const uint32_t first = seg.tile_seg[2 * tile];
   const int lane = (int)threadIdx.x;
@@ -669,7 +672,8 @@ __host__ __device__ inline void segment_thresholds(int32_t seg_cfg, int32_t heav
 __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __restrict__ tile_range, int num_tiles,
                                                            int32_t seg_cfg, int32_t heavy_cfg, int32_t needs_grad,
                                                            int64_t O, const uint32_t* __restrict__ O_dev,
-                                                           uint32_t capacity, uint32_t* __restrict__ tile_seg,
+                                                           uint32_t capacity, uint32_t heavy_capacity,
+                                                           uint32_t* __restrict__ tile_seg,
                                                            uint32_t* __restrict__ seg_desc,
                                                            uint32_t* __restrict__ seg_total) {
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
   const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
   // a heavy tile's segments are also FORWARD work units (alpha-product pass + a prologue over the preceding segments):
   // about 256 pairs each and at most ~128 per tile; a long tile's segments are only checkpoints: seg_pairs each
-  const bool heavy = len > heavy_min;
+  bool heavy = len > heavy_min;
   const uint32_t seg_heavy = max(seg_pairs, min(256u, (heavy_min / 2u) & ~3u));
   const uint32_t seg_t = heavy ? max(seg_heavy, (((len + 127u) / 128u) + 3u) & ~3u) : seg_pairs;
   uint32_t n = len > seg_pairs ? (len + seg_t - 1) / seg_t : 0u;
@@ -692,6 +696,19 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
         d[0] = (uint32_t)t; d[1] = a; d[2] = a; d[3] = 0u;
       }
       n = 0u;
+    }
+  }
+  // the segments of heavy tiles are also listed compactly (behind the tile table): the forward passes that only
+  // concern them launch one block per entry of that list instead of one per segment of the frame
+  if (n && heavy) {
+    const uint32_t hat = atomicAdd(seg_total + 1, n);
+    if (hat + n <= heavy_capacity) {
+      uint32_t* list = tile_seg + 2 * (size_t)num_tiles;
+      for (uint32_t j = 0; j < n; ++j) list[hat + j] = at + j;
+    } else {                  // cannot happen with the host's bound; stay in range regardless: the one-wave walk with
+      heavy = false;          // checkpoints takes the tile and the list's tail holds "no segment"
+      uint32_t* list = tile_seg + 2 * (size_t)num_tiles;
+      for (uint32_t j = hat; j < heavy_capacity; ++j) list[j] = 0xFFFFFFFFu;
     }
   }
   tile_seg[2 * t] = at;
@@ -716,7 +733,7 @@ inline SegDev to_segdev(const GsrSegmentsC* sg) {
 
 inline bool seg_ok(const GsrSegmentsC* sg, bool median) {
   if (!sg) return true;
-  if (sg->capacity <= 0) return false;
+  if (sg->capacity <= 0 || sg->heavy_capacity < 0 || sg->heavy_capacity > sg->capacity) return false;
   return sg->tile_seg && sg->seg_desc && sg->seg_total && sg->seg_P && sg->seg_TC && sg->seg_last &&
          (!median || sg->seg_median);
 }
@@ -754,16 +771,33 @@ int64_t gsr_segment_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cf
   return by_min < by_rule ? by_min : by_rule;
 }
 
+int64_t gsr_segment_heavy_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
+                                   int32_t num_tiles, int32_t needs_grad) {
+  if (O <= 0 || num_tiles <= 0) return 0;
+  // a heavy tile (len > heavy) is cut into pieces of at least seg_heavy = max(seg, min(256, heavy / 2)) pairs
+  uint32_t seg, heavy;
+  segment_thresholds(seg_pairs_cfg, heavy_min_cfg, O, num_tiles, needs_grad, &seg, &heavy);
+  if (O_is_bound && heavy_min_cfg <= 0) heavy = 512;                 // the automatic threshold of any smaller count
+  if (O_is_bound && seg_pairs_cfg <= 0) seg = needs_grad ? 64 : 256;
+  uint32_t piece = (heavy / 2u) & ~3u;
+  if (piece > 256u) piece = 256u;
+  if (piece < seg) piece = seg;
+  if (piece < 1u) piece = 1u;
+  return O / piece + O / ((int64_t)heavy + 1) + 1;
+}
+
 int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
-                     int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, uint32_t* tile_seg_out,
-                     uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream_) {
+                     int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, int64_t heavy_capacity,
+                     uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (num_tiles <= 0 || capacity <= 0 || capacity > 0x7fffffffll || (O < 0 && !O_dev)) return GSR_ERR_INVALID_ARGUMENT;
+  if (heavy_capacity < 0 || heavy_capacity > capacity) return GSR_ERR_INVALID_ARGUMENT;
   if (seg_pairs_cfg > 0 && heavy_min_cfg > 0 && heavy_min_cfg < seg_pairs_cfg) return GSR_ERR_INVALID_ARGUMENT;
   if (!tile_range || !tile_seg_out || !seg_desc_out || !seg_total_out) return GSR_ERR_INVALID_ARGUMENT;
   segment_plan_kernel<<<(num_tiles + 255) / 256, 256, 0, stream>>>(tile_range, num_tiles, seg_pairs_cfg, heavy_min_cfg,
-                                                                  needs_grad, O, O_dev, (uint32_t)capacity, tile_seg_out,
-                                                                  seg_desc_out, seg_total_out);
+                                                                  needs_grad, O, O_dev, (uint32_t)capacity,
+                                                                  (uint32_t)heavy_capacity, tile_seg_out, seg_desc_out,
+                                                                  seg_total_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
@@ -783,7 +817,7 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
   if (vis && !pair_vis_out) return GSR_ERR_INVALID_ARGUMENT;
   if (!seg_ok(segments_host, med)) return GSR_ERR_INVALID_ARGUMENT;
   const SegDev seg = to_segdev(segments_host);
-  const int cap = segments_host ? (int)segments_host->capacity : 0;
+  const int cap = segments_host ? (int)segments_host->heavy_capacity : 0;   // blocks of the heavy-tile passes
 #define GSR_LAUNCH_FWD(CC, VV, MM)                                                                                     \
   do {                                                                                                                 \
     composite_fwd_kernel<CC, VV, MM><<<nt + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, tx, \
@@ -792,7 +826,7 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
                                                                   seg);                                                \
     if (cap) {                                                                                                         \
       seg_composite_kernel<CC, VV, MM><<<cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, tx,    \
-                                                               rp, vis_partial_out, pair_vis_out, seg);                \
+                                                               nt, rp, vis_partial_out, pair_vis_out, seg);            \
       seg_combine_kernel<CC, MM><<<nt, 64, 0, stream>>>(W, H, tx, nt, image_out, final_T_out, last_out,                \
                                                         median_depth_out, seg);                                        \
     }                                                                                                                  \

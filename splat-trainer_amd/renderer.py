@@ -331,7 +331,7 @@ def _plan_segments(st: "_RasterState", num_tiles: int, pairs: int, pairs_dev: Op
   """List segmentation (composite.hip): tiles longer than the frame's segment length are cut into segments; returns the
   GsrSegmentsC the composite calls take, or None when switched off.  ``pairs`` is the frame's pair count, or -- with
   ``pairs_dev``, the device word holding the count -- only an upper bound on it: the tables are then sized for any
-  count up to the bound and the plan kernel reads the count itself.  ``seg_total``: a zero-initialised device word (the
+  count up to the bound and the plan kernel reads the count itself.  ``seg_total``: two zero-initialised device words (the
   plan kernel's tiles reserve their segment slots on it)."""
   st.segment_buffers = None
   if st.seg_pairs == 0:
@@ -341,17 +341,21 @@ def _plan_segments(st: "_RasterState", num_tiles: int, pairs: int, pairs_dev: Op
   cap = int(lib.gsr_segment_capacity(pairs, 0 if pairs_dev is None else 1, st.seg_pairs, st.seg_min, num_tiles, grads))
   if cap <= 0:
     return None
-  tables = torch.empty(2 * num_tiles + 4 * cap, dtype=torch.int32, device=dev)
-  tile_seg, seg_desc = tables[:2 * num_tiles], tables[2 * num_tiles:]
+  bound = 0 if pairs_dev is None else 1
+  heavy_cap = min(cap, int(lib.gsr_segment_heavy_capacity(pairs, bound, st.seg_pairs, st.seg_min, num_tiles, grads)))
+  # [tile table (2 per tile) | compact list of the heavy tiles' segments | segment descriptors (4 per segment)]
+  tables = torch.empty(2 * num_tiles + heavy_cap + 4 * cap, dtype=torch.int32, device=dev)
+  tile_seg, seg_desc = tables[:2 * num_tiles + heavy_cap], tables[2 * num_tiles + heavy_cap:]
   _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, st.seg_pairs, st.seg_min, grads, pairs, _ptr(pairs_dev),
-                                  cap, _ptr(tile_seg), _ptr(seg_desc), _ptr(seg_total), stream), "gsr_segment_plan")
+                                  cap, heavy_cap, _ptr(tile_seg), _ptr(seg_desc), _ptr(seg_total), stream),
+             "gsr_segment_plan")
   planes = 5 + (1 if st.want_median else 0)                       # (T, c0, c1, c2) interleaved + alpha products (+ median)
   pix = torch.empty(planes * cap * 256, dtype=torch.float32, device=dev)
   seg_last = torch.empty(cap * 256, dtype=torch.int32, device=dev)
   seg_TC, seg_P = pix[:4 * cap * 256], pix[4 * cap * 256:5 * cap * 256]
   seg_med = pix[5 * cap * 256:] if st.want_median else None
   st.segment_buffers = (tables, pix, seg_last, seg_total)           # kept alive until backward has run
-  return _lib.GsrSegmentsC(tile_seg.data_ptr(), seg_desc.data_ptr(), seg_total.data_ptr(), cap, seg_P.data_ptr(),
+  return _lib.GsrSegmentsC(tile_seg.data_ptr(), seg_desc.data_ptr(), seg_total.data_ptr(), cap, heavy_cap, seg_P.data_ptr(),
                            seg_TC.data_ptr(), seg_last.data_ptr(),
                            seg_med.data_ptr() if seg_med is not None else None)
 
@@ -454,7 +458,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     st.vis_partial = zeros[fixed_zeros:] if need_vis_partial else None
     st.pair_vis = torch.empty(capacity, dtype=torch.float32, device=dev) if need_vis_partial else None
     st.segments = _plan_segments(st, num_tiles, capacity, pairs_dev, dev, stream,
-                                 zeros[2 * M + 2 * num_tiles:2 * M + 2 * num_tiles + 1].view(torch.int32))
+                                 zeros[2 * M + 2 * num_tiles:2 * M + 2 * num_tiles + 2].view(torch.int32))
     timer = KERNEL_TIMER
     if timer is not None:
       timer.begin("composite_forward")

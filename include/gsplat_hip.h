@@ -165,16 +165,18 @@ int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, c
 int gsr_depth_key_range(float near_plane, float far_plane, uint32_t* bias_out, uint32_t* max_key_out);
 int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_key, uint32_t* keys_out, void* stream);
 /* For rank k in depth order (order[k] = splat): writes the 12-float record rec[k] and the number of tiles its
- * support touches; also screen_scale_out[splat] = (sigma_major, sigma_minor) in pixels (sqrt of the eigenvalues
- * of the blurred 2D covariance).  features: [M,C], C in {1,2,3}. */
+ * support touches (a tile counts when the support reaches the pixel centres of its upper or lower half); also
+ * screen_scale_out[splat] = (sigma_major, sigma_minor) in pixels (sqrt of the eigenvalues of the blurred 2D covariance)
+ * and tile_hits_out [M,4] uint32: which tiles of the splat's extent were counted and which halves of each, for
+ * gsr_tile_emit (opaque to the caller).  features: [M,C], C in {1,2,3}. */
 int gsr_tile_count(const float* gaussians2d, const float* depth, const float* features, const uint32_t* order,
                    int64_t M, int32_t C, int32_t W, int32_t H, const GsrRasterParamsC* params_host, float* rec_out,
-                   uint32_t* count_out, float* screen_scale_out, void* stream);
+                   uint32_t* count_out, float* screen_scale_out, uint32_t* tile_hits_out, void* stream);
 /* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id, inst2rank[...] = k.
  * capacity = number of entries the two output arrays hold: instances at or beyond it are dropped, so the call may be
  * enqueued into buffers sized from a guess while the exact total is still on its way to the host (the caller compares
  * the total with the capacity afterwards and emits again if it was too small). */
-int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
+int gsr_tile_emit(const float* rec, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M, int32_t W, int32_t H,
                   const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, int64_t capacity,
                   void* stream);
 /* From the tile-sorted keys: per-tile [start, end).  tile_range must be zero-filled by the caller:

@@ -70,8 +70,8 @@ PROTOTYPES = {
     "gsr_sh_backward_dense": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     "gsr_depth_key_range": (C.c_int, [_f, _f, _p, _p]),
     "gsr_depth_keys": (C.c_int, [_p, _i64, _u32, _u32, _p, _p]),
-    "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p]),
-    "gsr_tile_emit": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p]),
+    "gsr_tile_count": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p]),
+    "gsr_tile_emit": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p]),
     "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "gsr_segment_thresholds": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _p, _p]),
     "gsr_segment_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),

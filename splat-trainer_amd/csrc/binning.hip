@@ -3,8 +3,8 @@
 //
 // Splats are visited in DEPTH ORDER (rank k -> splat order[k]); instances are emitted rank-major, so the
 // instance stream is already depth-sorted and only a stable sort on the tile id is needed afterwards.
-// The per-tile test is exact for the ellipse {d^T conic d <= qmax} against the tile's rectangle of pixel
-// centres, with qmax shrunk for faint splats (alpha can only reach 1/255 inside 2 ln(255 opacity)).
+// The per-tile test is exact for the ellipse {d^T conic d <= qmax} against the rectangles of pixel centres of the
+// tile's two halves, with qmax shrunk for faint splats (alpha can only reach 1/255 inside 2 ln(255 opacity)).
 #include "gsr_device.h"
 #include "../../include/gsplat_hip.h"
 
@@ -24,13 +24,33 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(const float* __restrict
   keys[m] = gsr_depth_key(depth[m], bias, max_key);
 }
 
-__device__ __forceinline__ uint32_t count_tiles(float u, float v, float A, float B, float C, const GsrExtent& e) {
+// Which tiles of its extent does a splat touch, and which halves of each?  A tile counts when the support reaches the
+// pixel centres of its upper (bit 0) or lower (bit 1) half -- the two units the composite kernels evaluate; a support
+// that only crosses the centre-free strip between the halves contributes to no pixel and makes no pair.
+// K4 count stores the answer for the emit pass: extents of up to 32 tiles (all but splats hundreds of pixels wide) as a
+// 64-bit map, 2 bits per tile of the extent in row-major order; larger ones are flagged and tested again by the emit.
+struct TileHits {            // 16 bytes per depth rank
+  uint32_t origin;           // x0 | y0 << 16
+  uint32_t shape;            // nx | ny << 8 | (1 << 16 when the map does not fit: emit recomputes)
+  uint32_t lo, hi;           // the map
+};
+
+__device__ __forceinline__ uint32_t hits_of_large_extent(float u, float v, float A, float B, float C, const GsrExtent& e,
+                                                         uint32_t* keys, uint32_t* ranks, uint32_t o, uint32_t capacity,
+                                                         uint32_t k, int tiles_x) {
   uint32_t n = 0;
-  const int nx = e.x1 - e.x0, ny = e.y1 - e.y0;
-  if (nx <= 0 || ny <= 0) return 0;
-  if (nx == 1 && ny == 1) return gsr_tile_hit(u, v, A, B, C, e.qmax, e.x0, e.y0) ? 1u : 0u;
   for (int ty = e.y0; ty < e.y1; ++ty)
-    for (int tx = e.x0; tx < e.x1; ++tx) n += gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty) ? 1u : 0u;
+    for (int tx = e.x0; tx < e.x1; ++tx) {
+      if (!gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty)) continue;       // cheap rejection first: these extents are big
+      const uint32_t hm = gsr_tile_half_mask(u, v, A, B, C, e.qmax, tx, ty);
+      if (!hm) continue;
+      if (keys) {
+        if (o + n >= capacity) return n;      // speculative launch into buffers sized from a guess: the caller re-emits
+        keys[o + n] = (uint32_t)(ty * tiles_x + tx);
+        ranks[o + n] = k | (hm << 30);        // depth rank in the low 30 bits, the tile halves reached in the top 2
+      }
+      ++n;
+    }
   return n;
 }
 
@@ -39,7 +59,8 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict
                                                          const float* __restrict__ feat,
                                                          const uint32_t* __restrict__ order, int64_t M, int tiles_x,
                                                          int tiles_y, GsrRasterParams rp, float* __restrict__ rec,
-                                                         uint32_t* __restrict__ count, float* __restrict__ sscale) {
+                                                         uint32_t* __restrict__ count, float* __restrict__ sscale,
+                                                         TileHits* __restrict__ hits) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   const int64_t s = order[k];
@@ -54,8 +75,31 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict
   r[0] = make_float4(uv.x, uv.y, ab.x, ab.y);
   r[1] = make_float4(co.x, co.y, depth[s], f0);
   r[2] = make_float4(f1, f2, 0.f, 0.f);
-  GsrExtent e = gsr_splat_extent(uv.x, uv.y, ab.x, ab.y, co.x, co.y, rp, tiles_x, tiles_y);
-  count[k] = count_tiles(uv.x, uv.y, ab.x, ab.y, co.x, e);
+  const GsrExtent e = gsr_splat_extent(uv.x, uv.y, ab.x, ab.y, co.x, co.y, rp, tiles_x, tiles_y);
+  const int nx = e.x1 - e.x0, ny = e.y1 - e.y0;
+  TileHits h;
+  h.origin = (uint32_t)e.x0 | ((uint32_t)e.y0 << 16);
+  h.shape = 0u; h.lo = 0u; h.hi = 0u;
+  uint32_t n = 0;
+  if (nx > 0 && ny > 0) {
+    if (nx * ny <= 32) {
+      h.shape = (uint32_t)nx | ((uint32_t)ny << 8);
+      uint64_t map = 0ull;
+      int t = 0;
+      for (int ty = e.y0; ty < e.y1; ++ty)
+        for (int tx = e.x0; tx < e.x1; ++tx, ++t) {
+          const uint64_t hm = gsr_tile_half_mask(uv.x, uv.y, ab.x, ab.y, co.x, e.qmax, tx, ty);
+          map |= hm << (2 * t);
+          n += hm ? 1u : 0u;
+        }
+      h.lo = (uint32_t)map; h.hi = (uint32_t)(map >> 32);
+    } else {
+      h.shape = 1u << 16;
+      n = hits_of_large_extent(uv.x, uv.y, ab.x, ab.y, co.x, e, nullptr, nullptr, 0u, 0u, 0u, tiles_x);
+    }
+  }
+  count[k] = n;
+  *reinterpret_cast<uint4*>(hits + k) = make_uint4(h.origin, h.shape, h.lo, h.hi);
   // sigma = sqrt(eig(cov)), cov = conic^-1 = [C -B; -B A] / det(conic)
   const float idet = 1.f / (ab.x * co.x - ab.y * ab.y);
   const float mid = 0.5f * (ab.x + co.x) * idet;
@@ -64,26 +108,34 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict__ rec,
-                                                        const uint32_t* __restrict__ offsets, int64_t M, int tiles_x,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        const TileHits* __restrict__ hits, int64_t M, int tiles_x,
                                                         int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ keys,
                                                         uint32_t* __restrict__ inst2rank, uint32_t capacity) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
-  const float4* r = reinterpret_cast<const float4*>(rec + GSR_REC_FLOATS * k);
-  const float4 r0 = r[0];
-  const float4 r1 = r[1];
-  const float u = r0.x, v = r0.y, A = r0.z, B = r0.w, C = r1.x, op = r1.y;
-  GsrExtent e = gsr_splat_extent(u, v, A, B, C, op, rp, tiles_x, tiles_y);
+  const uint4 hw = *reinterpret_cast<const uint4*>(hits + k);
   uint32_t o = offsets[k];
-  for (int ty = e.y0; ty < e.y1; ++ty)
-    for (int tx = e.x0; tx < e.x1; ++tx)
-      if (gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty)) {
-        if (o >= capacity) return;            // speculative launch into buffers sized from a guess: the caller re-emits
-        keys[o] = (uint32_t)(ty * tiles_x + tx);
-        // depth rank in the low 30 bits, which tile halves the support reaches in the top 2
-        inst2rank[o] = (uint32_t)k | (gsr_tile_half_mask(u, v, A, B, C, e.qmax, tx, ty) << 30);
-        ++o;
-      }
+  if (hw.y >> 16) {                           // extent too large for the map: test again, exactly as the count pass did
+    const float4* r = reinterpret_cast<const float4*>(rec + GSR_REC_FLOATS * k);
+    const float4 r0 = r[0];
+    const float4 r1 = r[1];
+    const GsrExtent e = gsr_splat_extent(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rp, tiles_x, tiles_y);
+    hits_of_large_extent(r0.x, r0.y, r0.z, r0.w, r1.x, e, keys, inst2rank, o, capacity, (uint32_t)k, tiles_x);
+    return;
+  }
+  const int nx = (int)(hw.y & 0xFFu), ny = (int)((hw.y >> 8) & 0xFFu);
+  const int x0 = (int)(hw.x & 0xFFFFu), y0 = (int)(hw.x >> 16);
+  uint64_t map = (uint64_t)hw.z | ((uint64_t)hw.w << 32);
+  for (int j = 0; j < ny; ++j)
+    for (int i = 0; i < nx; ++i, map >>= 2) {
+      const uint32_t hm = (uint32_t)(map & 3ull);
+      if (!hm) continue;
+      if (o >= capacity) return;              // speculative launch into buffers sized from a guess: the caller re-emits
+      keys[o] = (uint32_t)((y0 + j) * tiles_x + x0 + i);
+      inst2rank[o] = (uint32_t)k | (hm << 30);   // depth rank in the low 30 bits, the tile halves reached in the top 2
+      ++o;
+    }
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, int64_t O,
@@ -208,23 +260,26 @@ int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_ke
 
 int gsr_tile_count(const float* gaussians2d, const float* depth, const float* features, const uint32_t* order,
                    int64_t M, int32_t C, int32_t W, int32_t H, const GsrRasterParamsC* params_host, float* rec_out,
-                   uint32_t* count_out, float* screen_scale_out, void* stream_) {
+                   uint32_t* count_out, float* screen_scale_out, uint32_t* tile_hits_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16 || C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!gaussians2d || !depth || !features || !order || !rec_out || !count_out || !screen_scale_out) return GSR_ERR_INVALID_ARGUMENT;
+  if (!gaussians2d || !depth || !features || !order || !rec_out || !count_out || !screen_scale_out || !tile_hits_out)
+    return GSR_ERR_INVALID_ARGUMENT;
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  if (tx > 0xFFFF || ty > 0xFFFF) return GSR_ERR_UNSUPPORTED;      // the hit records hold 16-bit tile coordinates
+  TileHits* hits = reinterpret_cast<TileHits*>(tile_hits_out);
   const GsrRasterParams rp = to_params(params_host);
   const unsigned g = grid_for(M, 256);
-  if (C == 1) tile_count_kernel<1><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out);
-  else if (C == 2) tile_count_kernel<2><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out);
-  else tile_count_kernel<3><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out);
+  if (C == 1) tile_count_kernel<1><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out, hits);
+  else if (C == 2) tile_count_kernel<2><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out, hits);
+  else tile_count_kernel<3><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out, hits);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
 
-int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t W, int32_t H,
+int gsr_tile_emit(const float* rec, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M, int32_t W, int32_t H,
                   const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, int64_t capacity,
                   void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -232,10 +287,11 @@ int gsr_tile_emit(const float* rec, const uint32_t* offsets, int64_t M, int32_t 
   if (capacity < 0 || capacity > 0x7FFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!rec || !offsets || !keys_out || !inst2rank_out) return GSR_ERR_INVALID_ARGUMENT;
+  if (!rec || !offsets || !tile_hits || !keys_out || !inst2rank_out) return GSR_ERR_INVALID_ARGUMENT;
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
-  tile_emit_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rec, offsets, M, tx, ty, to_params(params_host), keys_out,
-                                                        inst2rank_out, (uint32_t)capacity);
+  tile_emit_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rec, offsets, reinterpret_cast<const TileHits*>(tile_hits), M, tx,
+                                                        ty, to_params(params_host), keys_out, inst2rank_out,
+                                                        (uint32_t)capacity);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -397,6 +397,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
   st.count = _u32(M, dev)
   st.offsets = _u32(M, dev)
+  tile_hits = torch.empty(M, 4, dtype=torch.int32, device=dev)   # K4 count -> emit: the counted tiles of every splat
   # Everything that must start at zero comes out of ONE zero-filled allocation (one fill launch per frame): the
   # heuristics, the tile ranges, the segment counter, [number of overlaps, overflow flag] and the per-pair visibility.
   # Its size depends on the pair count, which is only guessed at this point (see below); a frame without a guess, or
@@ -416,8 +417,8 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   total = (zeros_guess[fixed_zeros - 2:fixed_zeros].view(torch.int32) if zeros_guess is not None else
            torch.zeros(2, dtype=torch.int32, device=dev))         # [number of overlaps, overflow flag]
   _lib.check(lib.gsr_tile_count(_ptr(g2d), _ptr(depth), _ptr(feats), _ptr(st.order), M, C_, W, H,
-                                C.byref(st.params), _ptr(st.rec), _ptr(st.count), _ptr(st.screen_scale), stream),
-             "gsr_tile_count")
+                                C.byref(st.params), _ptr(st.rec), _ptr(st.count), _ptr(st.screen_scale), _ptr(tile_hits),
+                                stream), "gsr_tile_count")
   scan_bytes = lib.gsr_scan_workspace_bytes(M)
   scan_ws = torch.empty(scan_bytes, dtype=torch.uint8, device=dev)
   _lib.check(lib.gsr_exclusive_scan_u32_checked(_ptr(st.count), _ptr(st.offsets), M, _ptr(total), _ptr(total[1:]),
@@ -429,7 +430,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     ``capacity`` pairs.  With ``pairs_dev`` (the device word with the pair count) the capacity is only a bound: every
     kernel that needs the count reads it there, so the whole chain is enqueued before the count has reached the host."""
     tkeys_a, trank_a = _u32(capacity, dev), _u32(capacity, dev)
-    _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), M, W, H, C.byref(st.params), _ptr(tkeys_a),
+    _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), _ptr(tile_hits), M, W, H, C.byref(st.params), _ptr(tkeys_a),
                                  _ptr(trank_a), capacity, stream), "gsr_tile_emit")
     tkeys_b, tvals_a, tvals_b, trank_b = _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev)
     if zeros is None:

@@ -130,12 +130,12 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
 }
 
 // ------------------------------------------------------------------------------------------ radix sort
-// Stable LSD radix sort, four launches per pass:
-//   rs_hist        per-block digit histogram (LDS atomics) -> hist[digit][block];  rs_row_total: totals per digit
-//   rs_digit_scan  one block per digit: base = sum of the totals of smaller digits, then an exclusive scan of the
-//                  digit's row over blocks
-//   rs_scatter     per-round (256 elements) ballot-match ranking inside each wave, wave counts through LDS;
-//                  elements keep their input order inside every digit bucket (stable).  Up to two value arrays.
+// Stable LSD radix sort, three launches per pass:
+//   rs_hist        per-block digit histogram (LDS atomics) -> hist[digit][block]
+//   rs_digit_scan  one block per digit: exclusive scan of the digit's row over the blocks, and the digit's total
+//   rs_scatter     digit bases from the totals (block scan), then per-round (256 elements) ballot-match ranking inside
+//                  each wave, wave counts through LDS; elements keep their input order inside every digit bucket
+//                  (stable).  Up to two value arrays.
 // Digits are 8 bits wide, or 9 (512 bins, two per thread) when that saves a pass: the depth keys of a frame span
 // bits(far) - bits(near), 27 bits for near 0.1 / far 100 -- three 9-bit passes instead of four 8-bit ones.
 constexpr int RS_THREADS = 256;
@@ -167,33 +167,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t* __r
   }
 }
 
-// one block per digit: total count of the digit over all blocks (global atomics on 256 hot words measured 3x slower)
-__global__ __launch_bounds__(RS_THREADS) void rs_row_total_kernel(const uint32_t* __restrict__ hist, uint32_t num_blocks,
-                                                                  uint32_t* __restrict__ digit_total) {
-  __shared__ uint32_t s_wave[4];
-  const uint32_t* row = hist + (size_t)blockIdx.x * num_blocks;
-  uint32_t t = 0;
-  for (uint32_t b = threadIdx.x; b < num_blocks; b += RS_THREADS) t += row[b];
-  t = gsr_wave_sum_u32(t);
-  if (gsr_lane() == 0) s_wave[threadIdx.x >> 6] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) digit_total[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-}
-
+// one block per digit: exclusive scan of the digit's row over the blocks (offsets RELATIVE to the digit's first element)
+// and the digit's total; the scatter kernel turns the totals into the digits' bases itself (a 256/512-wide block scan)
 __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(const uint32_t* __restrict__ hist,
                                                                    uint32_t* __restrict__ offs, uint32_t num_blocks,
-                                                                   const uint32_t* __restrict__ digit_total) {
+                                                                   uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_carry;
   const uint32_t d = blockIdx.x;
   const int lane = gsr_lane(), wave = threadIdx.x >> 6;
-  // base of this digit = total count of all smaller digits (the grid has one block per digit: 256 or 512)
-  uint32_t t = 0;
-  for (uint32_t j = threadIdx.x; j < d; j += RS_THREADS) t += digit_total[j];
-  t = gsr_wave_sum_u32(t);
-  if (lane == 0) s_wave[wave] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) s_carry = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  if (threadIdx.x == 0) s_carry = 0u;
   __syncthreads();
   const uint32_t* row = hist + (size_t)d * num_blocks;
   uint32_t* orow = offs + (size_t)d * num_blocks;
@@ -215,6 +198,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(const uint32_
     if (threadIdx.x == 0) s_carry += total;
     __syncthreads();
   }
+  if (threadIdx.x == 0) digit_total[d] = s_carry;
 }
 
 // Stable scatter with LDS staging.  The block's elements are first placed, digit-bucket by digit-bucket, into an LDS
@@ -230,6 +214,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
                                                                 uint32_t* __restrict__ vals2_out, uint32_t n, int shift,
                                                                 uint32_t mask, const uint32_t* __restrict__ counts,
                                                                 const uint32_t* __restrict__ offsets,
+                                                                const uint32_t* __restrict__ digit_total,
                                                                 uint32_t num_blocks, const uint32_t* __restrict__ n_dev) {
   constexpr int TILE = ROUNDS * RS_THREADS;
   constexpr int BINS = 1 << BITS, PER = BINS / RS_THREADS;     // thread t owns the consecutive digits PER t .. PER t + PER - 1
@@ -239,32 +224,38 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
   __shared__ uint32_t s_goff[BINS];           // global slot of the digit's first element of this block
   __shared__ uint32_t s_run[BINS];            // elements of the digit placed by earlier rounds
   __shared__ uint32_t s_wcnt[4][BINS];        // per-wave digit counts of the current round
-  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_wave[4], s_wave_t[4];
   __shared__ uint32_t s_key[TILE];
   __shared__ uint32_t s_val[TILE];
   __shared__ uint32_t s_val2[TWO ? TILE : 1];
   const int lane = gsr_lane(), wave = threadIdx.x >> 6;
   {
-    uint32_t c[PER], mine = 0;
+    // two block-wide exclusive scans over the digits: this block's counts -> first image slot of each digit; the
+    // digits' totals -> global base of each digit (+ the elements of the digit in earlier blocks = its global slot)
+    uint32_t c[PER], t[PER], mine = 0, mine_t = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const uint32_t d = PER * threadIdx.x + k;
       c[k] = counts[(size_t)d * num_blocks + blockIdx.x];
-      s_goff[d] = offsets[(size_t)d * num_blocks + blockIdx.x];
+      t[k] = digit_total[d];
       s_run[d] = 0;
       mine += c[k];
+      mine_t += t[k];
     }
-    const uint32_t incl = gsr_wave_scan_incl_u32(mine);
-    if (lane == 63) s_wave[wave] = incl;
+    const uint32_t incl = gsr_wave_scan_incl_u32(mine), incl_t = gsr_wave_scan_incl_u32(mine_t);
+    if (lane == 63) { s_wave[wave] = incl; s_wave_t[wave] = incl_t; }
     __syncthreads();
-    uint32_t at = incl - mine;
+    uint32_t at = incl - mine, base = incl_t - mine_t;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-      if (w < wave) at += s_wave[w];
+      if (w < wave) { at += s_wave[w]; base += s_wave_t[w]; }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      s_start[PER * threadIdx.x + k] = at;
+      const uint32_t d = PER * threadIdx.x + k;
+      s_start[d] = at;
+      s_goff[d] = base + offsets[(size_t)d * num_blocks + blockIdx.x];
       at += c[k];
+      base += t[k];
     }
   }
   const uint32_t base = blockIdx.x * (uint32_t)TILE;
@@ -333,9 +324,9 @@ size_t sort_ws_bytes(int64_t n) {
 template <bool TWO, int ROUNDS, int BITS>
 void rs_launch_scatter(uint32_t nb, hipStream_t stream, const uint32_t* kin, const uint32_t* vin, const uint32_t* v2in,
                        uint32_t* kout, uint32_t* vout, uint32_t* v2out, uint32_t n, int bit, uint32_t mask,
-                       const uint32_t* hist, const uint32_t* offs, const uint32_t* n_dev) {
+                       const uint32_t* hist, const uint32_t* offs, const uint32_t* totals, const uint32_t* n_dev) {
   rs_scatter_kernel<TWO, ROUNDS, BITS><<<nb, RS_THREADS, 0, stream>>>(kin, vin, v2in, kout, vout, v2out, n, bit, mask, hist,
-                                                                      offs, nb, n_dev);
+                                                                      offs, totals, nb, n_dev);
 }
 
 template <int BITS>
@@ -366,16 +357,14 @@ int sort_passes(uint32_t* keys_a, uint32_t* vals_a, uint32_t* vals2_a, uint32_t*
     uint32_t* tot = totals + (size_t)p * RS_MAX_BINS;
     rs_hist_kernel<BITS><<<nb, RS_THREADS, 0, stream>>>(kin, (uint32_t)n, bit, mask, rounds, hist, nb, n_dev);
     GSR_CHECK_LAUNCH();
-    rs_row_total_kernel<<<BINS, RS_THREADS, 0, stream>>>(hist, nb, tot);
-    GSR_CHECK_LAUNCH();
     rs_digit_scan_kernel<<<BINS, RS_THREADS, 0, stream>>>(hist, offs, nb, tot);
     GSR_CHECK_LAUNCH();
     if (two) {
-      if (rounds == 4) rs_launch_scatter<true, 4, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
-      else rs_launch_scatter<true, 16, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
+      if (rounds == 4) rs_launch_scatter<true, 4, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, tot, n_dev);
+      else rs_launch_scatter<true, 16, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, tot, n_dev);
     } else {
-      if (rounds == 4) rs_launch_scatter<false, 4, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
-      else rs_launch_scatter<false, 16, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, n_dev);
+      if (rounds == 4) rs_launch_scatter<false, 4, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, tot, n_dev);
+      else rs_launch_scatter<false, 16, BITS>(nb, stream, kin, vin, v2in, kout, vout, v2out, (uint32_t)n, bit, mask, hist, offs, tot, n_dev);
     }
     GSR_CHECK_LAUNCH();
     where ^= 1;

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 }
 
 // out[i] = block_offsets[b] + exclusive prefix inside the block.  block_offsets may be null (single block).
+// SELF: block_offsets holds the blocks' RAW sums (scan_reduce's output) and every block adds up its predecessors'
+// itself -- for up to a few thousand blocks that is cheaper than a launch that scans the sums in between.
 // The grand total (sum of everything) is written to *total_out by the last block when total_out != null.
+template <bool SELF>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* in, uint32_t n,   // in may alias out
                                                                   const uint32_t* __restrict__ block_offsets,
                                                                   uint32_t* out, uint32_t* __restrict__ total_out,
@@ -83,8 +86,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
   }
   uint32_t total;
   uint32_t excl = block_scan_excl(sum, &total);
-  uint32_t boff = block_offsets ? block_offsets[blockIdx.x] : 0u;
-  if (overflow) flag_if_large(fsum, boff, overflow);
+  uint32_t boff = 0u;
+  if (SELF) {
+    uint32_t before = 0;
+    float fbefore = 0.f;                                     // the same sum in float: range check only (see flag_if_large)
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += SCAN_THREADS) {
+      const uint32_t b = block_offsets[j];
+      before += b;
+      fbefore += (float)b;
+    }
+    block_scan_excl(before, &boff);                          // boff = total over the block = sum of all earlier blocks
+    fsum += fbefore;                                         // flag_if_large sums fsum over the block
+  } else if (block_offsets) {
+    boff = block_offsets[blockIdx.x];
+  }
+  if (overflow) flag_if_large(fsum, SELF ? 0u : boff, overflow);
   uint32_t run = boff + excl;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
@@ -95,6 +111,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
   if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = boff + total;
 }
 
+constexpr uint32_t SCAN_SELF_PREFIX_MAX_BLOCKS = 4096;       // 16 M elements: 16 KB of sums read per block at most
 
 size_t scan_ws_bytes(uint64_t n) {
   size_t bytes = 0;
@@ -114,7 +131,7 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
   }
   uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
   if (nb == 1) {
-    scan_apply_kernel<<<1, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, nullptr, out, total_dev, overflow);
+    scan_apply_kernel<false><<<1, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, nullptr, out, total_dev, overflow);
     GSR_CHECK_LAUNCH();
     return GSR_OK;
   }
@@ -122,9 +139,14 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
   size_t used = (((size_t)nb * sizeof(uint32_t) + 255) / 256) * 256;
   scan_reduce_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, overflow);
   GSR_CHECK_LAUNCH();
+  if (nb <= SCAN_SELF_PREFIX_MAX_BLOCKS) {
+    scan_apply_kernel<true><<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, out, total_dev, overflow);
+    GSR_CHECK_LAUNCH();
+    return GSR_OK;
+  }
   int rc = scan_impl(block_sums, block_sums, nb, nullptr, ws + used, stream, overflow);   // in place
   if (rc != GSR_OK) return rc;
-  scan_apply_kernel<<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, out, total_dev, overflow);
+  scan_apply_kernel<false><<<nb, SCAN_THREADS, 0, stream>>>(in, (uint32_t)n, block_sums, out, total_dev, overflow);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

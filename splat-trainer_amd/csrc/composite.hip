@@ -763,11 +763,12 @@ int64_t gsr_segment_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cf
     return O / seg + O / ((int64_t)seg + 1) + 1;
   }
   // only a bound on the pair count is known and the segment length follows the true count: for any count <= O the
-  // automatic length is >= 64; while it is below 256 it is >= count / (6 tiles), i.e. <= 6 segments per tile on
-  // average, plus one remainder per tile; at 256 the first formula applies
+  // automatic length is >= 64; while it is below 256 it is >= floor(count / (6 tiles)) >= 64, i.e. at most
+  // 6 (1 + 1/64) segments per tile on average, plus one remainder per tile; at 256 the first formula applies
   const int64_t by_min = O / 64 + O / 65 + 1;
   const int64_t T = num_tiles;
-  const int64_t by_rule = (7 * T > O / 256 + T ? 7 * T : O / 256 + T) + 1;
+  const int64_t small = 7 * T + T / 8 + 1;
+  const int64_t by_rule = (small > O / 256 + T ? small : O / 256 + T) + 1;
   return by_min < by_rule ? by_min : by_rule;
 }
 

@@ -34,7 +34,7 @@ class RasterConfig:
   compute_visibility: bool = False    # fill points.visibility (sum_pixels T*alpha) in forward
   compute_point_heuristic: bool = False  # fill prune_cost / split_score in backward
   segment_pairs: int = -1             # list segments of a tile: length in (tile, splat) pairs; -1 = chosen per frame,
-                                      # 0 = no segmentation at all (renderer._segment_thresholds)
+                                      # 0 = no segmentation at all (rule: csrc/composite.hip segment_thresholds, gsr_segment_thresholds)
   segment_min_pairs: int = 0          # a tile is heavy (its FORWARD pass is segmented too) above this many pairs;
                                       # 0 = chosen per frame from the overlap count
 

@@ -316,16 +316,6 @@ def _launch_depth_order(depth: torch.Tensor, M: int, key_range, keys: Optional[t
   return vals_b if where == 1 else vals_a
 
 
-def _segment_thresholds(seg_pairs: int, seg_min: int, O: int, num_tiles: int, needs_grad: bool):
-  """(segment length, heavy-tile threshold) a frame with O pairs is cut with; explicit config values win, negative /
-  zero mean automatic.  The rule lives in the library (composite.hip: segment_thresholds), where the plan kernel
-  evaluates it too -- possibly from a pair count that is still on the device."""
-  seg, heavy = C.c_int32(0), C.c_int32(0)
-  _lib.check(_lib.load().gsr_segment_thresholds(int(seg_pairs), int(seg_min), int(O), int(num_tiles), int(bool(needs_grad)),
-                                                C.byref(seg), C.byref(heavy)), "gsr_segment_thresholds")
-  return seg.value, heavy.value
-
-
 def _plan_segments(st: "_RasterState", num_tiles: int, pairs: int, pairs_dev: Optional[torch.Tensor], dev, stream,
                    seg_total: torch.Tensor):
   """List segmentation (composite.hip): tiles longer than the frame's segment length are cut into segments; returns the

@@ -42,6 +42,42 @@ def test_host_only_entry_points(built_libs):
   assert C.sizeof(_lib.GsrRasterParamsC) == 32
 
 
+def test_segment_rule_and_capacity_bounds(built_libs):
+  """Host side of the list segmentation (no GPU needed): the per-frame thresholds, and the buffer bounds -- the bound
+  for "at most O pairs" (what the renderer sizes its tables with before the pair count is known) must cover the exact
+  bound of every smaller frame, for the segment table and for the heavy-tile list alike."""
+  lib = _lib.load()
+
+  def thresholds(seg, heavy, O, tiles, grads):
+    a, b = C.c_int32(0), C.c_int32(0)
+    assert lib.gsr_segment_thresholds(seg, heavy, O, tiles, grads, C.byref(a), C.byref(b)) == 0
+    return a.value, b.value
+
+  assert thresholds(-1, 0, 1_465_883, 8160, 1) == (64, 625)           # c2: ~180 pairs per tile -> 64-pair segments
+  assert thresholds(-1, 0, 6_593_876, 8160, 1) == (136, 2393)         # c3: mean list / 6, heavy = 120 + O / 2900
+  assert thresholds(-1, 0, 6_593_876, 8160, 0) == (1196, 2393)        # evaluation: only heavy tiles are cut
+  assert thresholds(-1, 0, 100, 12, 1) == (64, 512)
+  assert thresholds(8, 20, 10 ** 6, 100, 1) == (8, 20)                # explicit values win
+  assert thresholds(40, 0, 0, 100, 1) == (40, 512)
+  import random
+  rnd = random.Random(1)
+  for _ in range(3000):
+    tiles = rnd.choice([1, 12, 300, 8160, 32400])
+    bound = rnd.randint(1, 40_000_000)
+    grads = rnd.randint(0, 1)
+    seg_cfg, heavy_cfg = rnd.choice([(-1, 0), (-1, 0), (0 + 16, 64), (4, 0), (-1, 900)])
+    cap_bound = lib.gsr_segment_capacity(bound, 1, seg_cfg, heavy_cfg, tiles, grads)
+    hcap_bound = lib.gsr_segment_heavy_capacity(bound, 1, seg_cfg, heavy_cfg, tiles, grads)
+    for O in (bound, bound // 2, bound // 7 + 1, rnd.randint(1, bound)):
+      seg, heavy = thresholds(seg_cfg, heavy_cfg, O, tiles, grads)
+      # the most segments a frame of O pairs on `tiles` tiles can produce: every cut tile yields <= len / seg + 1
+      worst = O // seg + min(tiles, O // (seg + 1))
+      assert cap_bound >= min(worst, lib.gsr_segment_capacity(O, 0, seg_cfg, heavy_cfg, tiles, grads)), (tiles, bound, O)
+      piece = max(seg, min(256, (heavy // 2) & ~3), 1)
+      worst_heavy = O // piece + min(tiles, O // (heavy + 1))
+      assert hcap_bound >= min(worst_heavy, lib.gsr_segment_heavy_capacity(O, 0, seg_cfg, heavy_cfg, tiles, grads)), (tiles, bound, O)
+
+
 def test_no_cpu_fallback():
   g = sta.Gaussians3D(torch.randn(4, 3), torch.randn(4, 4), torch.randn(4, 3), torch.randn(4, 1), torch.randn(4, 3))
   cam = sta.CameraParams(torch.eye(4), torch.tensor([50., 50., 16., 16.]), (32, 32))

@@ -558,3 +558,17 @@ def test_image_is_bit_identical_in_every_mode_of_the_same_frame():
       for median in (False, True):
         r = sta.render_gaussians(scene, cam, cfg, use_sh=True, render_median_depth=median)
         assert torch.equal(r.image, base[0]), (cfg.compute_visibility, median, float((r.image - base[0]).abs().max()))
+
+
+@pytest.mark.parametrize("near,far", [(0.0, 100.0), (1e-6, 1e30), (0.1, float("inf")), (0.5, 20.0), (1e-3, 1e3)])
+def test_depth_key_range_follows_the_camera_planes(near, far):
+  """The depth sort's keys are taken relative to the near plane and sorted over bits(far) - bits(near) only (3 radix
+  passes for 0.1 .. 100); cameras without a usable range (near = 0, far infinite or huge) fall back to plain 32-bit
+  keys.  The frame must come out the same whatever the planes are, as long as every splat lies between them."""
+  g, cam = small_scene(800, 96, 64, sh_degree=2, seed=11, sigma_px=3.0)
+  ref_cam = sta.CameraParams(cam.T_camera_world, cam.projection, cam.image_size, 0.01, 1000.0)
+  want = hip_render_and_grads(g, ref_cam, CFG, use_sh=True)
+  got = hip_render_and_grads(g, sta.CameraParams(cam.T_camera_world, cam.projection, cam.image_size, near, far), CFG, use_sh=True)
+  assert torch.equal(got["idx"], want["idx"]) and got["num_overlaps"] == want["num_overlaps"]
+  for k in ("image", "visibility", "split_score", "prune_cost") + GRADS:
+    assert torch.equal(got[k], want[k]), k

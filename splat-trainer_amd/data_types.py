@@ -168,36 +168,64 @@ def _detach(value: Any) -> Any:
     return value.detach()
   if hasattr(value, "detach"):
     return value.detach()
-  return value
+  return value            # incl. an unresolved visibility resolver (RenderedPoints): stays lazy
 
 
-@dataclass
 class RenderedPoints:
   """Per-point outputs for the M points that passed the frustum cull.
 
-  ``visibility`` is filled by the forward pass (compute_visibility); ``prune_cost`` and
-  ``split_score`` are owned by this object and filled **in place by backward**
+  ``visibility`` (compute_visibility) is readable as soon as the forward pass has been enqueued;
+  ``prune_cost`` and ``split_score`` are owned by this object and filled **in place by backward**
   (compute_point_heuristic) -- the reference reads them after ``loss.backward()``
   (trainer.py:512-514).
+
+  ``visibility`` may be handed in as a zero-argument resolver instead of a tensor: the renderer's backward pass
+  delivers the per-splat sums as a by-product of its own reduction, so a frame that is back-propagated before anybody
+  looks at the visibility never runs the separate forward-side reduction; a reader that comes first (``points.visible``
+  in a regularizer, mlp_scene.py:268-288) triggers it on access.  Same sums in the same order either way: same bits.
   """
-  idx: torch.Tensor                   # (M,) int64 indices into the scene's N points
-  depths: torch.Tensor                # (M, 1) camera-space z (differentiable)
-  opacity: torch.Tensor               # (M,)  (differentiable)
-  screen_scale: torch.Tensor          # (M, 2) sigma_major, sigma_minor in pixels
-  visibility: torch.Tensor            # (M,)
-  prune_cost: torch.Tensor            # (M,)
-  split_score: torch.Tensor           # (M,)
-  attributes: Any = None              # user payload (mlp_scene.py:423)
+  FIELDS = ("idx", "depths", "opacity", "screen_scale", "visibility", "prune_cost", "split_score", "attributes")
+
+  def __init__(self, idx: torch.Tensor, depths: torch.Tensor, opacity: torch.Tensor, screen_scale: torch.Tensor,
+               visibility, prune_cost: torch.Tensor, split_score: torch.Tensor, attributes: Any = None):
+    self.idx = idx                      # (M,) int64 indices into the scene's N points
+    self.depths = depths                # (M, 1) camera-space z (differentiable)
+    self.opacity = opacity              # (M,)  (differentiable)
+    self.screen_scale = screen_scale    # (M, 2) sigma_major, sigma_minor in pixels
+    self._visibility = visibility       # (M,) tensor, or a resolver returning it
+    self.prune_cost = prune_cost        # (M,)
+    self.split_score = split_score      # (M,)
+    self.attributes = attributes        # user payload (mlp_scene.py:423)
+
+  @property
+  def visibility(self) -> torch.Tensor:
+    v = self._visibility
+    if v is not None and not isinstance(v, torch.Tensor):
+      v = self._visibility = v()
+    return v
+
+  @visibility.setter
+  def visibility(self, value):
+    self._visibility = value
 
   @property
   def batch_size(self):
     return (self.idx.shape[0],)
 
+  def _raw(self, name):
+    return self._visibility if name == "visibility" else getattr(self, name)
+
+  def to_dict(self) -> dict:
+    return {n: getattr(self, n) for n in self.FIELDS}
+
   def replace(self, **kwargs) -> "RenderedPoints":
-    return _dc_replace(self, **kwargs)
+    unknown = set(kwargs) - set(self.FIELDS)
+    if unknown:
+      raise TypeError(f"RenderedPoints.replace: unknown field(s) {sorted(unknown)}")
+    return RenderedPoints(**{n: kwargs[n] if n in kwargs else self._raw(n) for n in self.FIELDS})
 
   def __getitem__(self, rows) -> "RenderedPoints":
-    return RenderedPoints(**{f.name: _index_rows(getattr(self, f.name), rows) for f in fields(self)})
+    return RenderedPoints(**{n: _index_rows(getattr(self, n), rows) for n in self.FIELDS})
 
   @property
   def visible_mask(self) -> torch.Tensor:
@@ -212,7 +240,10 @@ class RenderedPoints:
     return int(self.visible_mask.sum().item())
 
   def detach(self) -> "RenderedPoints":
-    return RenderedPoints(**{f.name: _detach(getattr(self, f.name)) for f in fields(self)})
+    return RenderedPoints(**{n: _detach(self._raw(n)) for n in self.FIELDS})
+
+  def __repr__(self):
+    return f"RenderedPoints(M={self.idx.shape[0]})"
 
 
 @dataclass

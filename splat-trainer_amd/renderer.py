@@ -30,7 +30,7 @@ from .data_types import CameraParams, Gaussians3D, RasterConfig, RenderedPoints,
 from . import sh as _sh
 from .sh import evaluate_sh_at
 
-REC_FLOATS = 12
+ROW_FLOATS = 16          # packed per-splat row (64 bytes; include/gsplat_hip.h GSR_ROW_FLOATS)
 PARTIAL_FLOATS = 12
 
 
@@ -270,10 +270,22 @@ def project_to_image(gaussians: Gaussians3D, camera_params: CameraParams, config
 # ------------------------------------------------------------------------------------------- K4..K7
 class _RasterState:
   """Per-frame buffers shared by forward and backward (owned by the autograd node / the Rendering)."""
-  __slots__ = ("M", "O", "C", "W", "H", "params", "rec", "order", "count", "offsets", "sorted_rank",
+  __slots__ = ("M", "O", "C", "W", "H", "params", "rows", "order", "count", "offsets", "sorted_splat",
                "sorted_inst", "tile_range", "vis_partial", "pair_vis", "final_T", "last", "median", "visibility",
                "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad",
-               "segments", "segment_buffers", "seg_pairs", "seg_min", "image", "key_range")
+               "segments", "segment_buffers", "seg_pairs", "seg_min", "image", "key_range", "vis_ready", "vis_capacity")
+
+  def materialize_visibility(self) -> torch.Tensor:
+    """points.visibility = per-splat sum of the forward pass's per-pair partials.  A frame that is back-propagated gets
+    it from the backward pass's own reduction (one column of the packed gradient rows, same sums in the same order:
+    same bits); whoever reads it EARLIER -- a regularizer on ``points.visible`` before ``loss.backward()``,
+    mlp_scene.py:268-288 -- triggers the stand-alone reduction here, once."""
+    if not self.vis_ready:
+      _lib.check(_lib.load().gsr_reduce_visibility(_ptr(self.vis_partial), _ptr(self.offsets), _ptr(self.count),
+                                                   _ptr(self.order), self.M, _ptr(self.visibility), self.vis_capacity,
+                                                   _stream()), "gsr_reduce_visibility")
+      self.vis_ready = True
+    return self.visibility
 
 
 def _u32(n: int, device) -> torch.Tensor:
@@ -297,12 +309,12 @@ def _depth_key_range(near: float, far: float):
   return hit
 
 
-def _launch_depth_order(depth: torch.Tensor, M: int, key_range, keys: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _launch_depth_order(depth: Optional[torch.Tensor], M: int, key_range, keys: Optional[torch.Tensor] = None) -> torch.Tensor:
   """depth keys + stable radix sort of the M splats over the keys' significant bits (ties keep ascending index); returns
   order (M,) int32.  ``key_range`` = _depth_key_range(near, far); ``keys``: the keys when K2 has already written them
   (consumed as sort scratch)."""
   lib = _lib.load()
-  dev = depth.device
+  dev = keys.device if keys is not None else depth.device
   stream = _stream()
   bias, max_key, key_bits = key_range
   keys_a = keys if keys is not None else _u32(M, dev)
@@ -354,10 +366,12 @@ def _seg_ref(st: "_RasterState"):
   return C.byref(st.segments) if st.segments is not None else None
 
 
-def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tensor, st: _RasterState,
-                       need_vis_partial: bool, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _bin_and_composite(rows: torch.Tensor, st: _RasterState, need_vis_partial: bool,
+                       order: Optional[torch.Tensor] = None, depth: Optional[torch.Tensor] = None) -> torch.Tensor:
+  """K4 -> K5 -> K6 over the packed (M,16) rows (``st.screen_scale`` is already set by whoever made the rows).
+  ``order``: the depth order when it has been enqueued already; otherwise it is formed here from ``depth`` (M,)."""
   lib = _lib.load()
-  dev = g2d.device
+  dev = rows.device
   M, C_, W, H = st.M, st.C, st.W, st.H
   stream = _stream()
   tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
@@ -372,19 +386,19 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     st.last = torch.zeros(H, W, dtype=torch.int32, device=dev)
     st.median = torch.zeros(H, W, dtype=torch.float32, device=dev) if st.want_median else None
     st.visibility = torch.zeros(M, dtype=torch.float32, device=dev)
+    st.vis_ready = True
     return torch.zeros(H, W, C_, dtype=torch.float32, device=dev)
 
   if M == 0:
     heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))
     st.screen_scale = torch.zeros(0, 2, dtype=torch.float32, device=dev)
     return blank()
-  st.screen_scale = torch.empty(M, 2, dtype=torch.float32, device=dev)   # written for every splat by K4
+  st.rows = rows
 
   # depth order of the M splats (stable: ties keep ascending index); project_to_image may already have enqueued it
   st.order = order if order is not None else _launch_depth_order(depth, M, st.key_range)
 
-  # per-splat tile counts + depth-ordered records
-  st.rec = torch.empty(M, REC_FLOATS, dtype=torch.float32, device=dev)
+  # per-splat tile counts (the one gather through the depth order: a 64-byte row per splat)
   st.count = _u32(M, dev)
   st.offsets = _u32(M, dev)
   tile_hits = torch.empty(M, 4, dtype=torch.int32, device=dev)   # K4 count -> emit: the counted tiles of every splat
@@ -406,8 +420,7 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   zeros_guess = zero_block(guess) if guess > 0 else None
   total = (zeros_guess[fixed_zeros - 2:fixed_zeros].view(torch.int32) if zeros_guess is not None else
            torch.zeros(2, dtype=torch.int32, device=dev))         # [number of overlaps, overflow flag]
-  _lib.check(lib.gsr_tile_count(_ptr(g2d), _ptr(depth), _ptr(feats), _ptr(st.order), M, C_, W, H,
-                                C.byref(st.params), _ptr(st.rec), _ptr(st.count), _ptr(st.screen_scale), _ptr(tile_hits),
+  _lib.check(lib.gsr_tile_count(_ptr(rows), _ptr(st.order), M, W, H, C.byref(st.params), _ptr(st.count), _ptr(tile_hits),
                                 stream), "gsr_tile_count")
   scan_bytes = lib.gsr_scan_workspace_bytes(M)
   scan_ws = torch.empty(scan_bytes, dtype=torch.uint8, device=dev)
@@ -420,8 +433,8 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     ``capacity`` pairs.  With ``pairs_dev`` (the device word with the pair count) the capacity is only a bound: every
     kernel that needs the count reads it there, so the whole chain is enqueued before the count has reached the host."""
     tkeys_a, trank_a = _u32(capacity, dev), _u32(capacity, dev)
-    _lib.check(lib.gsr_tile_emit(_ptr(st.rec), _ptr(st.offsets), _ptr(tile_hits), M, W, H, C.byref(st.params), _ptr(tkeys_a),
-                                 _ptr(trank_a), capacity, stream), "gsr_tile_emit")
+    _lib.check(lib.gsr_tile_emit(_ptr(rows), _ptr(st.order), _ptr(st.offsets), _ptr(tile_hits), M, W, H, C.byref(st.params),
+                                 _ptr(tkeys_a), _ptr(trank_a), capacity, stream), "gsr_tile_emit")
     tkeys_b, tvals_a, tvals_b, trank_b = _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev)
     if zeros is None:
       zeros = zero_block(capacity)
@@ -432,16 +445,17 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     st.last = torch.empty(H, W, dtype=torch.int32, device=dev)
     st.median = torch.empty(H, W, dtype=torch.float32, device=dev) if st.want_median else None
     st.visibility = (torch.empty if st.compute_visibility else torch.zeros)(M, dtype=torch.float32, device=dev)
+    st.vis_ready, st.vis_capacity = not st.compute_visibility, capacity
 
     # stable-sort the pairs by tile id, find per-tile ranges
     tile_bits = max(1, int(math.ceil(math.log2(num_tiles)))) if num_tiles > 1 else 1
     tsort_bytes = lib.gsr_sort_workspace_bytes(capacity)
     tsort_ws = torch.empty(tsort_bytes, dtype=torch.uint8, device=dev)
-    # values: instance id (implicit 0..O-1) and depth rank travel with the tile key
+    # values: instance id (implicit 0..O-1) and splat id (+ half mask) travel with the tile key
     where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(tkeys_a), _ptr(tvals_a), _ptr(trank_a), _ptr(tkeys_b), _ptr(tvals_b),
                                                _ptr(trank_b), capacity, 1, 0, tile_bits, _ptr(tsort_ws), tsort_bytes,
                                                _ptr(pairs_dev), stream), "gsr_sort_pairs2_u32(tile)")
-    sorted_keys, st.sorted_inst, st.sorted_rank = (tkeys_b, tvals_b, trank_b) if where == 1 else (tkeys_a, tvals_a, trank_a)
+    sorted_keys, st.sorted_inst, st.sorted_splat = (tkeys_b, tvals_b, trank_b) if where == 1 else (tkeys_a, tvals_a, trank_a)
     st.tile_range = zeros[2 * M:2 * M + 2 * num_tiles].view(torch.int32).view(num_tiles, 2)
     _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), capacity, num_tiles, _ptr(st.tile_range), _ptr(pairs_dev), stream),
                "gsr_tile_ranges")
@@ -453,15 +467,14 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
     timer = KERNEL_TIMER
     if timer is not None:
       timer.begin("composite_forward")
-    _lib.check(lib.gsr_composite_forward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
+    _lib.check(lib.gsr_composite_forward(_ptr(rows), _ptr(st.sorted_splat), _ptr(st.sorted_inst),
                                          _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
                                          _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
                                          _ptr(st.pair_vis), _seg_ref(st), stream), "gsr_composite_forward")
     if timer is not None:
       timer.end("composite_forward")
-    if st.compute_visibility:
-      _lib.check(lib.gsr_reduce_visibility(_ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count), _ptr(st.order),
-                                           M, _ptr(st.visibility), capacity, stream), "gsr_reduce_visibility")
+    if st.compute_visibility and not st.needs_grad:
+      st.materialize_visibility()       # no backward pass will deliver it: reduce the per-pair partials now
     return image
 
   # The O-sized buffers are sized from the totals of the frames before and the whole chain is enqueued BEFORE this frame's
@@ -483,11 +496,55 @@ def _bin_and_composite(g2d: torch.Tensor, feats: torch.Tensor, depth: torch.Tens
   return image
 
 
+def _composite_backward_rows(st: _RasterState, d_image: Optional[torch.Tensor], dev) -> torch.Tensor:
+  """K7 + the per-splat reduction: the packed (M,16) gradient rows of the frame
+  (du dv dA dB | dC dop prune split | df0 df1 df2 visibility | 0 0 0 0), zeros when nothing was composited."""
+  lib = _lib.load()
+  live = st.M > 0 and st.O > 0 and d_image is not None
+  if not live:
+    return torch.zeros(st.M, ROW_FLOATS, dtype=torch.float32, device=dev)
+  if st.vis_partial is None:
+    raise _lib.GsplatHipError("backward called on a rendering made without gradient state")
+  stream = _stream()
+  dimg = _f32c(d_image)
+  partial = torch.empty(st.O, PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+  timer = KERNEL_TIMER
+  if timer is not None:
+    timer.begin("composite_backward")
+  _lib.check(lib.gsr_composite_backward(_ptr(st.rows), _ptr(st.sorted_splat), _ptr(st.sorted_inst),
+                                        _ptr(st.pair_vis), _ptr(st.tile_range), st.W, st.H, st.C,
+                                        C.byref(st.params), _ptr(st.final_T), _ptr(st.last), _ptr(dimg),
+                                        _ptr(st.image), _ptr(partial), _seg_ref(st), stream),
+             "gsr_composite_backward")
+  if timer is not None:
+    timer.end("composite_backward")
+  grows = torch.empty(st.M, ROW_FLOATS, dtype=torch.float32, device=dev)      # every row is written whole
+  _lib.check(lib.gsr_reduce_gradients(_ptr(partial), _ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count),
+                                      _ptr(st.order), st.M, _ptr(grows), stream), "gsr_reduce_gradients")
+  return grows
+
+
+def _vis_out(st: _RasterState, live: bool):
+  """Where the backward pass leaves points.visibility (None: nothing to deliver, or it has been reduced already)."""
+  if live and st.compute_visibility and not st.vis_ready:
+    st.vis_ready = True
+    return st.visibility
+  return None
+
+
 class _RasterFn(torch.autograd.Function):
+  """K4..K7 of the three-call form: the caller's (M,6) / (M,C) / (M,1) tensors are packed into the (M,16) rows the
+  kernels read, and the packed gradient rows are taken apart again for the caller's graph."""
+
   @staticmethod
   def forward(ctx, g2d, feats, depth, st: _RasterState, order):
+    lib = _lib.load()
     g, f, d = _f32c(g2d), _f32c(feats), _f32c(depth).reshape(-1)
-    image = _bin_and_composite(g, f, d, st, need_vis_partial=st.compute_visibility or st.needs_grad, order=order)
+    rows = torch.empty(st.M, ROW_FLOATS, dtype=torch.float32, device=g.device)
+    st.screen_scale = torch.empty(st.M, 2, dtype=torch.float32, device=g.device)
+    _lib.check(lib.gsr_pack_rows(_ptr(g), _ptr(d), _ptr(f), st.M, st.C, _ptr(rows), _ptr(st.screen_scale), _stream()),
+               "gsr_pack_rows")
+    image = _bin_and_composite(rows, st, need_vis_partial=st.compute_visibility or st.needs_grad, order=order, depth=d)
     st.image = image.detach() if st.needs_grad else None     # segment blocks of the backward pass need the final colour
     ctx.st = st
     ctx.in_dtypes = (g2d.dtype, feats.dtype)      # e.g. fp16 colours from an autocast MLP (mlp_scene.py:362)
@@ -499,31 +556,126 @@ class _RasterFn(torch.autograd.Function):
     st: _RasterState = ctx.st
     dev = d_image.device
     live = st.M > 0 and st.O > 0
-    alloc = torch.empty if live else torch.zeros                # the per-splat reduction writes every row
+    alloc = torch.empty if live else torch.zeros                # the unpack sweep writes every row
     d_g2d = alloc(st.M, 6, dtype=torch.float32, device=dev)
     d_feat = alloc(st.M, st.C, dtype=torch.float32, device=dev)
     if live:
-      if st.vis_partial is None:
-        raise _lib.GsplatHipError("backward called on a rendering made without gradient state")
-      stream = _stream()
-      dimg = _f32c(d_image)
-      partial = torch.empty(st.O, PARTIAL_FLOATS, dtype=torch.float32, device=dev)
-      timer = KERNEL_TIMER
-      if timer is not None:
-        timer.begin("composite_backward")
-      _lib.check(lib.gsr_composite_backward(_ptr(st.rec), _ptr(st.sorted_rank), _ptr(st.sorted_inst),
-                                            _ptr(st.pair_vis), _ptr(st.tile_range), st.W, st.H, st.C,
-                                            C.byref(st.params), _ptr(st.final_T), _ptr(st.last), _ptr(dimg),
-                                            _ptr(st.image), _ptr(partial), _seg_ref(st), stream),
-                 "gsr_composite_backward")
-      if timer is not None:
-        timer.end("composite_backward")
-      # prune_cost / split_score are written straight into the tensors the Rendering already holds
-      _lib.check(lib.gsr_reduce_gradients(_ptr(partial), _ptr(st.vis_partial), _ptr(st.offsets), _ptr(st.count),
-                                          _ptr(st.order), st.M, st.C, _ptr(d_g2d), _ptr(d_feat),
-                                          _ptr(st.prune_cost), _ptr(st.split_score), stream),
-                 "gsr_reduce_gradients")
+      grows = _composite_backward_rows(st, d_image, dev)
+      # prune_cost / split_score (/ visibility) are written straight into the tensors the Rendering already holds
+      _lib.check(lib.gsr_unpack_grad_rows(_ptr(grows), st.M, st.C, _ptr(d_g2d), _ptr(d_feat), _ptr(st.prune_cost),
+                                          _ptr(st.split_score), _ptr(_vis_out(st, live)), _stream()),
+                 "gsr_unpack_grad_rows")
     return d_g2d.to(ctx.in_dtypes[0]), d_feat.to(ctx.in_dtypes[1]), None, None, None
+
+
+class _FrameFn(torch.autograd.Function):
+  """The one-call form with SH colours as ONE autograd node: K1 cull -> fused K2 + K3 (one packed 64-byte row per
+  visible splat) -> K4..K6; backward = K7 -> packed gradient rows -> one sweep in splat order for the geometry
+  gradients and the per-point outputs -> SH coefficient gradient.  Outputs: image, gaussians2d (M,6) and depth (M,1)
+  (views of the rows; differentiable, so regularizers on points.opacity / points.depths reach the parameters), indexes."""
+
+  @staticmethod
+  def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T, proj, cam_pos, cull_args, st: _RasterState,
+              grad_out, sh_out, want_pos_grad):
+    lib = _lib.load()
+    pos, ls, rot, al = _f32c(position), _f32c(log_scaling), _f32c(rotation), _f32c(alpha_logit)
+    sh, cam = _f32c(feature), _f32c(cam_pos)
+    N, K, dev = pos.shape[0], sh.shape[2], pos.device
+    W, H, near, far, margin = cull_args
+    stream = _stream()
+    indexes_full = torch.empty(N, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.gsr_cull_workspace_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rows_full = torch.empty(N, ROW_FLOATS, dtype=torch.float32, device=dev)
+    scale_full = torch.empty(N, 2, dtype=torch.float32, device=dev)
+    keys_full = _u32(N, dev)
+    # d colour / d position is cheap to form while the coefficient row is in registers; saving it (36 B per splat)
+    # spares the backward pass a second sweep over the 12K-byte rows
+    jac_full = torch.empty(N, 9, dtype=torch.float32, device=dev) if (want_pos_grad and K > 1 and N > 0) else None
+    key_range = st.key_range
+    _lib.check(lib.gsr_frustum_cull(_ptr(pos), N, _ptr(T), _ptr(proj), W, H, near, far, margin, _ptr(indexes_full),
+                                    _ptr(count), _ptr(ws), ws_bytes, stream), "gsr_frustum_cull")
+    # enqueued with the visible count still on the device: the GPU works through the rows while the host reads it back
+    _lib.check(lib.gsr_project_sh_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(sh), K, _ptr(indexes_full), N,
+                                          _ptr(T), _ptr(proj), _ptr(cam), C.byref(st.params), _ptr(rows_full),
+                                          _ptr(scale_full), _ptr(jac_full), _ptr(count), _ptr(keys_full), key_range[0],
+                                          key_range[1], stream), "gsr_project_sh_forward")
+    M = int(_start_readback(count)()[0])       # host sync #1: the size of ``indexes`` is data dependent
+    indexes, rows = indexes_full[:M], rows_full[:M]
+    st.M, st.screen_scale = M, scale_full[:M]
+    order = _launch_depth_order(None, M, key_range, keys=keys_full[:M]) if M > 0 else None
+    image = _bin_and_composite(rows, st, need_vis_partial=st.compute_visibility or st.needs_grad, order=order)
+    st.image = image.detach() if st.needs_grad else None
+    ctx.save_for_backward(pos, ls, rot, al, sh, indexes, T, proj, cam)
+    ctx.set_materialize_grads(False)       # unused outputs (gaussians2d / depth, usually) arrive as None
+    ctx.st, ctx.jac = st, (jac_full[:M] if jac_full is not None else None)
+    ctx.grad_out, ctx.sh_out = grad_out, sh_out
+    ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype, feature.dtype)
+    ctx.mark_non_differentiable(indexes)
+    return image, rows[:, 0:6], rows[:, 6:7], indexes
+
+  @staticmethod
+  def backward(ctx, d_image, d_g2d, d_depth, _d_indexes):
+    lib = _lib.load()
+    pos, ls, rot, al, sh, indexes, T, proj, cam = ctx.saved_tensors
+    st: _RasterState = ctx.st
+    M, N, K, dev = indexes.shape[0], pos.shape[0], sh.shape[2], pos.device
+    go, sh_out = ctx.grad_out, ctx.sh_out
+    collector = sh_out if isinstance(sh_out, _sh.ShFactorCollector) else None
+    nothing = (None,) * 13
+    if go is not None:
+      d_pos, d_ls = go._check("position", pos), go._check("log_scaling", ls)
+      d_rot, d_al = go._check("rotation", rot), go._check("alpha_logit", al)
+    else:
+      alloc = torch.empty_like if (M == N and M > 0) else torch.zeros_like   # every row is written when nothing was culled
+      d_pos, d_ls, d_rot, d_al = alloc(pos), alloc(ls), alloc(rot), alloc(al)
+    # the SH coefficient gradient: to the factor collector (data-parallel), into caller-owned buffers, or returned
+    want_sh = collector is not None or sh_out is not None or ctx.needs_input_grad[4]
+    d_sh = None
+    if M > 0:
+      live = st.O > 0 and d_image is not None
+      grows = _composite_backward_rows(st, d_image, dev)
+      dg = _f32c(d_g2d) if d_g2d is not None else None
+      dd = _f32c(d_depth).reshape(-1) if d_depth is not None else None
+      dcol = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_sh else None
+      _lib.check(lib.gsr_project_backward_rows(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M, _ptr(T),
+                                               _ptr(proj), C.byref(st.params), _ptr(grows), _ptr(dg), _ptr(dd),
+                                               _ptr(ctx.jac), _ptr(d_pos), _ptr(d_ls), _ptr(d_rot), _ptr(d_al),
+                                               1 if go is not None else 0, _ptr(dcol),
+                                               _ptr(st.prune_cost) if live else None,
+                                               _ptr(st.split_score) if live else None, _ptr(_vis_out(st, live)),
+                                               _stream()), "gsr_project_backward_rows")
+    else:
+      dcol = torch.zeros(0, 3, dtype=torch.float32, device=dev) if want_sh else None
+    if collector is not None:              # data-parallel factor exchange: keep only the colour gradient
+      collector.items.append((indexes, dcol, cam))
+    elif want_sh:
+      owner = sh_out[2] if (sh_out is not None and len(sh_out) > 2) else None
+      overwrite = sh_out is None or (owner is not None and owner.feature_uninitialized)
+      d_sh = sh_out[0] if sh_out is not None else torch.empty(N, 3, K, dtype=torch.float32, device=dev)
+      if overwrite and N > 0 and (M == N or 8 * M >= N):
+        # every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no read-modify-write
+        inv = None
+        if M < N:
+          inv = torch.empty(N, dtype=torch.int32, device=dev)
+          _lib.check(lib.gsr_inverse_map(_ptr(indexes), M, N, _ptr(inv), _stream()), "gsr_inverse_map")
+        _lib.check(lib.gsr_sh_backward_dense(_ptr(dcol), _ptr(sh), _ptr(pos), _ptr(inv), M, N, K, _ptr(cam), None,
+                                             _ptr(d_sh), None, _stream()), "gsr_sh_backward_dense")
+      else:
+        if overwrite:
+          d_sh.zero_()
+        if M > 0:
+          _lib.check(lib.gsr_sh_backward(_ptr(dcol), _ptr(sh), _ptr(pos), _ptr(indexes), M, K, _ptr(cam), None,
+                                         _ptr(d_sh), None, 1, _stream()), "gsr_sh_backward")
+      if owner is not None:
+        owner.feature_uninitialized = False
+    if go is not None:
+      return (None, None, None, None, d_sh.to(ctx.in_dtypes[4]) if (d_sh is not None and sh_out is None) else None) + \
+          nothing[5:]
+    dt = ctx.in_dtypes
+    return (d_pos.to(dt[0]), d_ls.to(dt[1]), d_rot.to(dt[2]), d_al.to(dt[3]),
+            d_sh.to(dt[4]) if (d_sh is not None and sh_out is None) else None) + nothing[5:]
 
 
 def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features: torch.Tensor,
@@ -543,22 +695,30 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
   W, H = camera_params.image_size
   st = _RasterState()
   st.M, st.C, st.W, st.H = int(gaussians2d.shape[0]), int(features.shape[1]), int(W), int(H)
-  st.params = _lib.raster_params(config)
-  st.want_median = bool(render_median_depth)
-  st.compute_visibility = bool(config.compute_visibility or config.compute_point_heuristic)
-  st.vis_partial = None
-  st.pair_vis = None
-  st.segments = None
-  st.segment_buffers = None
-  st.seg_pairs, st.seg_min = int(config.segment_pairs), int(config.segment_min_pairs)
-  st.key_range = _depth_key_range(float(camera_params.near_plane), float(camera_params.far_plane))
+  _init_state(st, camera_params, config, render_median_depth)
   st.needs_grad = torch.is_grad_enabled() and (gaussians2d.requires_grad or features.requires_grad)
   order = None
   if _depth_order is not None and _depth_order[1] is depth and _depth_order[2] == depth._version:
     order = _depth_order[0]                 # enqueued by project_to_image(prefetch=...) for exactly this tensor
   image = _RasterFn.apply(gaussians2d, features, depth, st, order)
+  return _rendering_of(st, image, indexes, gaussians2d, depth, camera_params)
+
+
+def _init_state(st: _RasterState, camera_params: CameraParams, config: RasterConfig, render_median_depth: bool):
+  st.params = _lib.raster_params(config)
+  st.want_median = bool(render_median_depth)
+  st.compute_visibility = bool(config.compute_visibility or config.compute_point_heuristic)
+  st.vis_partial = st.pair_vis = st.segments = st.segment_buffers = st.rows = st.image = None
+  st.vis_ready, st.vis_capacity = True, 0
+  st.seg_pairs, st.seg_min = int(config.segment_pairs), int(config.segment_min_pairs)
+  st.key_range = _depth_key_range(float(camera_params.near_plane), float(camera_params.far_plane))
+
+
+def _rendering_of(st: _RasterState, image, indexes, gaussians2d, depth, camera_params) -> Rendering:
+  # visibility: the tensor when it exists already, otherwise the state's resolver (see _RasterState.materialize_visibility)
   points = RenderedPoints(idx=indexes, depths=depth, opacity=gaussians2d[:, 5], screen_scale=st.screen_scale,
-                          visibility=st.visibility, prune_cost=st.prune_cost, split_score=st.split_score)
+                          visibility=st.visibility if st.vis_ready else st.materialize_visibility,
+                          prune_cost=st.prune_cost, split_score=st.split_score)
   return Rendering(image=image, camera=camera_params, points=points, median_depth_image=st.median,
                    final_transmittance=st.final_T, num_overlaps=st.O)
 
@@ -567,29 +727,52 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
                      use_sh: bool = False, render_median_depth: bool = False, grad_out: Optional[GradOut] = None,
                      sh_collector=None, **options) -> Rendering:
   """One-call form (splat_trainer/scripts/test_split.py:30): project -> colour -> rasterize.
-  ``use_sh``: ``gaussians.feature`` is (N, 3, K) SH coefficients evaluated towards the camera;
-  otherwise it is an (N, C) per-point colour."""
+  ``use_sh``: ``gaussians.feature`` is (N, 3, K) SH coefficients evaluated towards the camera (one fused autograd node,
+  ``_FrameFn``); otherwise it is an (N, C) per-point colour and the three calls are chained."""
   config = config or RasterConfig()
+  feature = gaussians.feature
+  if use_sh and feature.is_cuda and feature.dim() == 3 and feature.shape[1] == 3 and feature.shape[2] in (1, 4, 9, 16):
+    return _render_frame(gaussians, camera_params, config, render_median_depth, grad_out, sh_collector)
   prefetch = {}
-  sh_out = None
   if use_sh:
+    sh_out = None
     if sh_collector is not None:            # data-parallel: exchange colour-gradient factors, not d_sh (sh.py)
       sh_out = sh_collector
     elif grad_out is not None:
-      sh_out = (grad_out._check("feature", gaussians.feature), grad_out._check("position", gaussians.position), grad_out)
-    camera_pos = camera_params.camera_position
-    if SPECULATE and gaussians.feature.is_cuda and gaussians.feature.dim() == 3 and \
-        gaussians.feature.shape[2] in (1, 4, 9, 16):
-      # K3 rides behind K1 + K2 inside project_to_image, before the visible count has reached the host
-      prefetch["sh"] = (gaussians.feature, gaussians.position, camera_pos,
-                        _sh.wants_position_grad(gaussians.position, sh_out))
-  g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out, prefetch=prefetch)
-  if use_sh:
-    feats = evaluate_sh_at(gaussians.feature, gaussians.position, indexes, camera_pos, grad_out=sh_out,
-                           _precomputed=prefetch.pop("sh_out", None))
+      sh_out = (grad_out._check("feature", feature), grad_out._check("position", gaussians.position), grad_out)
+    g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out, prefetch=prefetch)
+    feats = evaluate_sh_at(feature, gaussians.position, indexes, camera_params.camera_position, grad_out=sh_out)
   else:
     if grad_out is not None:
       raise ValueError("grad_out with use_sh=False: gather the features yourself or use plain autograd")
-    feats = gaussians.feature[indexes]
+    g2d, depth, indexes = project_to_image(gaussians, camera_params, config, grad_out=grad_out, prefetch=prefetch)
+    feats = feature[indexes]
   return render_projected(indexes, g2d, feats, depth, camera_params, config,
                           render_median_depth=render_median_depth, _depth_order=prefetch.get("depth_order"), **options)
+
+
+def _render_frame(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig, render_median_depth: bool,
+                  grad_out: Optional[GradOut], sh_collector) -> Rendering:
+  """render_gaussians(use_sh=True) through the fused node."""
+  position, feature = gaussians.position, gaussians.feature
+  _require_device(position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit, feature)
+  if config.tile_size != 16:
+    raise ValueError("the HIP kernels are specialised for tile_size=16")
+  sh_out = None
+  if sh_collector is not None:              # data-parallel: exchange colour-gradient factors, not d_sh (sh.py)
+    sh_out = sh_collector
+  elif grad_out is not None:
+    sh_out = (grad_out._check("feature", feature), grad_out._check("position", position), grad_out)
+  W, H = camera_params.image_size
+  st = _RasterState()
+  st.M, st.C, st.W, st.H, st.O = 0, 3, int(W), int(H), 0
+  _init_state(st, camera_params, config, render_median_depth)
+  st.needs_grad = torch.is_grad_enabled() and (grad_out is not None or sh_collector is not None or any(
+      t.requires_grad for t in (position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit, feature)))
+  cull_args = (int(W), int(H), float(camera_params.near_plane), float(camera_params.far_plane),
+               float(config.margin_tiles * config.tile_size))
+  image, g2d, depth, indexes = _FrameFn.apply(position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit,
+                                              feature, _f32c(camera_params.T_camera_world),
+                                              _f32c(camera_params.projection), camera_params.camera_position, cull_args,
+                                              st, grad_out, sh_out, _sh.wants_position_grad(position, sh_out))
+  return _rendering_of(st, image, indexes, g2d, depth, camera_params)

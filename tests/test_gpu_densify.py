@@ -154,7 +154,7 @@ def test_point_state_add_matches_the_reference_arithmetic():
                              prune_cost=torch.rand(m, generator=gen) * 10 ** (4 * torch.rand(m, generator=gen) - 2) * (vis > 0),
                              split_score=torch.rand(m, generator=gen) * (vis > 0))
     cpu_state.add_rendering(sta.Rendering(image=None, camera=None, points=pts))
-    dev_pts = sta.RenderedPoints(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in vars(pts).items()})
+    dev_pts = sta.RenderedPoints(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in pts.to_dict().items()})
     dev_state.add_rendering(sta.Rendering(image=None, camera=None, points=dev_pts))
   assert torch.equal(dev_state.max_scale_px.cpu(), cpu_state.max_scale_px)
   assert torch.equal(dev_state.points_in_view.cpu(), cpu_state.points_in_view)

@@ -497,7 +497,9 @@ def test_speculative_emit_and_early_colours_do_not_change_results():
   ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
   assert torch.equal(r.image.detach(), first_large["image"])
   assert torch.equal(gd.feature.grad, first_large["d_feature"])
-  assert torch.equal(gd.position.grad, first_large["d_position"])
+  # the geometry gradients come out of differently fused kernels in the two forms (K2 backward alone vs K2 backward +
+  # the colour gradient's position term in one sweep): same arithmetic, the compiler may contract other fma pairs
+  assert rel_err(gd.position.grad, first_large["d_position"]) < 1e-6
 
 
 def test_overlap_count_overflow_is_reported_not_wrapped():

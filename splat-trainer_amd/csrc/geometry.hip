@@ -122,45 +122,63 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restric
 // Colour of one splat from its coefficient row (and, JAC, d colour / d position through the view direction d = v/|v|).
 // Shared by the stand-alone K3 kernel and the fused K2+K3 kernel: explicit fma chains wherever the colour is formed, so
 // every instantiation (JAC or not, fused or not) rounds identically.
+// Core: the 3K coefficients are in registers already (from global memory or from an LDS-staged copy).  ONE sweep over k
+// feeds the three colours and (JAC) their derivatives wrt the view direction: dY_k is formed where it is consumed, so
+// only the coefficients and the K basis values are live across the sweep.
 template <int K, bool JAC>
-__device__ __forceinline__ void gsr_sh_colour(const float* __restrict__ row, float dx, float dy, float dz, float col[3],
-                                              float J[9]) {
+__device__ __forceinline__ void gsr_sh_colour_w(const float (&w)[3][K], float dx, float dy, float dz, float col[3],
+                                                float J[9]) {
   const float inv = 1.f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
   const float x = dx * inv, y = dy * inv, z = dz * inv;
   float Y[K];
   gsr_sh_basis<K>(x, y, z, Y);
-  float dYx[K], dYy[K], dYz[K];
-  if (JAC) gsr_sh_basis_grad<K>(x, y, z, dYx, dYy, dYz);
+  float acc[3] = {0.5f, 0.5f, 0.5f};
+  float g[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) acc[ch] = fmaf(w[ch][k], Y[k], acc[ch]);   // per channel: the same fma chain over k
+    if (JAC && k > 0) {
+      float ax, ay, az;
+      gsr_sh_basis_grad_at<K>(k, x, y, z, ax, ay, az);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        g[ch][0] += w[ch][k] * ax; g[ch][1] += w[ch][k] * ay; g[ch][2] += w[ch][k] * az;
+      }
+    }
+  }
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    // one sweep over the coefficient row feeds both the colour and (JAC) its derivative wrt the view direction
-    float acc = 0.5f, gx = 0.f, gy = 0.f, gz = 0.f;
-    float w[K];
+    col[ch] = acc[ch];
+    if (JAC) {
+      // d colour_ch / d position; saved (36 B per splat) so that the backward pass does not have to stream the
+      // 12K-byte coefficient row again
+      const float dot = g[ch][0] * x + g[ch][1] * y + g[ch][2] * z;
+      J[3 * ch] = (g[ch][0] - x * dot) * inv;
+      J[3 * ch + 1] = (g[ch][1] - y * dot) * inv;
+      J[3 * ch + 2] = (g[ch][2] - z * dot) * inv;
+    }
+  }
+}
+
+template <int K, bool JAC>
+__device__ __forceinline__ void gsr_sh_colour(const float* __restrict__ row, float dx, float dy, float dz, float col[3],
+                                              float J[9]) {
+  float w[3][K];                     // all 3K coefficients first (3K/4 16-byte loads in flight)
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
     if (K % 4 == 0) {
 #pragma unroll
       for (int k = 0; k < K; k += 4) {
         const float4 v = *reinterpret_cast<const float4*>(row + ch * K + k);
-        w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+        w[ch][k] = v.x; w[ch][k + 1] = v.y; w[ch][k + 2] = v.z; w[ch][k + 3] = v.w;
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < K; ++k) w[k] = row[ch * K + k];
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      acc = fmaf(w[k], Y[k], acc);
-      if (JAC && k > 0) { gx += w[k] * dYx[k]; gy += w[k] * dYy[k]; gz += w[k] * dYz[k]; }
-    }
-    col[ch] = acc;
-    if (JAC) {
-      // d colour_ch / d position; saved (36 B per splat) so that the backward pass does not have to stream the
-      // 12K-byte coefficient row again
-      const float dot = gx * x + gy * y + gz * z;
-      J[3 * ch] = (gx - x * dot) * inv;
-      J[3 * ch + 1] = (gy - y * dot) * inv;
-      J[3 * ch + 2] = (gz - z * dot) * inv;
+      for (int k = 0; k < K; ++k) w[ch][k] = row[ch * K + k];
     }
   }
+  gsr_sh_colour_w<K, JAC>(w, dx, dy, dz, col, J);
 }
 
 template <int K, bool JAC>
@@ -197,6 +215,21 @@ __device__ __forceinline__ float2 gsr_screen_scale(float A, float B, float C) {
 // Everything downstream of the projection -- K4's gather through the depth order, the scalar record loads of K6 / K7 --
 // reads this row and nothing else, so the depth-order permutation costs one line per splat instead of one per source
 // array.  Also written: screen_scale (M,2), the depth sort's keys, and (JAC) d colour / d position for the backward pass.
+// The coefficient rows (12K bytes each, 192 B at degree 3 -- 5/6 of what this kernel reads) are staged through LDS: the
+// block's 256 rows are fetched with fully coalesced 16-byte loads (consecutive lanes walk along a row, so every wave
+// instruction covers whole 64-byte lines instead of 64 different ones) and each thread then takes its own row out of
+// LDS.  Odd row pitch (3K or 3K + 1 words): conflict-free 4-byte LDS accesses, and at degree 3 three blocks (48 waves'
+// worth of rows would not fit with a 16-byte aligned pitch) share a CU's 160 KB.
+#ifndef GSR_PSF_STAGE_OUT
+#define GSR_PSF_STAGE_OUT 1
+#endif
+template <int K>
+struct ShStage {
+  static constexpr int ROW = 3 * K;
+  static constexpr bool VEC = (ROW % 4) == 0;
+  static constexpr int PITCH = ROW | 1;
+};
+
 template <int K, bool JAC>
 __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
     const float* __restrict__ pos, const float* __restrict__ ls, const float* __restrict__ rot,
@@ -204,17 +237,95 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
     const float* __restrict__ Tcw, const float* __restrict__ proj, const float* __restrict__ cam_pos,
     GsrRasterParams rp, float* __restrict__ rows, float* __restrict__ sscale, float* __restrict__ jac,
     const uint32_t* __restrict__ count_dev, uint32_t* __restrict__ depth_keys, uint32_t key_bias, uint32_t key_max) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
+  constexpr int ROW = ShStage<K>::ROW, PITCH = ShStage<K>::PITCH;
+  constexpr int OUT_FLOATS = GSR_PSF_STAGE_OUT ? 256 * (GSR_ROW_FLOATS + 1 + 9) : 0;     // rows + Jacobians on the way out
+  constexpr int STAGE_FLOATS = 256 * PITCH > OUT_FLOATS ? 256 * PITCH : OUT_FLOATS;
+  __shared__ float s_rows[STAGE_FLOATS];
+  __shared__ int32_t s_idx[256];
+  // M is an upper bound when count_dev is given: the true count is still on the device (K1 just produced it)
+  const int64_t count = count_dev ? min(M, (int64_t)*count_dev) : M;
+  const int64_t m0 = (int64_t)blockIdx.x * 256;
+  if (m0 >= count) return;                                   // block-uniform
+  const int tid = (int)threadIdx.x;
+  const int64_t m = m0 + tid;
+  const bool valid = m < count;
+  const int64_t i = valid ? idx[m] : -1;
+  s_idx[tid] = (int32_t)i;                                    // N <= 2^31 - 1 (gsr_frustum_cull)
+  __syncthreads();
+  if (ShStage<K>::VEC) {
+    constexpr int PARTS = ROW / 4;                             // 16-byte pieces per row
+#pragma unroll
+    for (int it = 0; it < PARTS; ++it) {
+      const int e = it * 256 + tid;
+      const int row = e / PARTS, part = e - row * PARTS;
+      const int64_t src = s_idx[row];
+      if (src >= 0) {
+        const float4 v = *reinterpret_cast<const float4*>(sh + src * ROW + 4 * part);
+        float* dst = s_rows + row * PITCH + 4 * part;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < ROW; ++it) {
+      const int e = it * 256 + tid;
+      const int row = e / ROW, col = e - row * ROW;
+      const int64_t src = s_idx[row];
+      if (src >= 0) s_rows[row * PITCH + col] = sh[src * ROW + col];
+    }
+  }
+  __syncthreads();
   const GsrCam cam = gsr_load_cam(Tcw, proj);
-  const int64_t i = idx[m];
-  float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-  float s[3] = {ls[3 * i], ls[3 * i + 1], ls[3 * i + 2]};
-  const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * i);
+  const int64_t ii = valid ? i : idx[m0];                     // threads past the count redo the block's first row (unused)
+  float p[3] = {pos[3 * ii], pos[3 * ii + 1], pos[3 * ii + 2]};
+  float s[3] = {ls[3 * ii], ls[3 * ii + 1], ls[3 * ii + 2]};
+  const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * ii);
   float q[4] = {qv.x, qv.y, qv.z, qv.w};
-  const GsrProjected o = gsr_project_one(cam, rp, p, s, q, logit[i]);
+  const GsrProjected o = gsr_project_one(cam, rp, p, s, q, logit[ii]);
+  float w[3][K];
+  const float* mine = s_rows + tid * PITCH;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[ch][k] = mine[ch * K + k];
   float col[3], J[9];
-  gsr_sh_colour<K, JAC>(sh + (int64_t)3 * K * i, p[0] - cam_pos[0], p[1] - cam_pos[1], p[2] - cam_pos[2], col, J);
+  gsr_sh_colour_w<K, JAC>(w, p[0] - cam_pos[0], p[1] - cam_pos[1], p[2] - cam_pos[2], col, J);
+#if GSR_PSF_STAGE_OUT
+  // The rows and the Jacobians leave through LDS as well: the block's 256 x 64 B (and 256 x 36 B) are contiguous in
+  // memory, so the staged copy goes out with fully coalesced 16-byte stores (whole lines per wave instruction) instead
+  // of four (nine) stores per thread at a 64-byte (36-byte) stride.
+  __syncthreads();                                            // every thread has taken its coefficients out of s_rows
+  constexpr int OP = GSR_ROW_FLOATS + 1;                      // odd pitch: conflict-free
+  float* s_out = s_rows;
+  float* s_jac = s_rows + 256 * OP;
+  if (valid) {
+    float* d = s_out + tid * OP;
+    d[0] = o.u; d[1] = o.v; d[2] = o.A; d[3] = o.B; d[4] = o.C; d[5] = o.opacity; d[6] = o.depth; d[7] = col[0];
+    d[8] = col[1]; d[9] = col[2]; d[10] = 0.f; d[11] = 0.f; d[12] = 0.f; d[13] = 0.f; d[14] = 0.f; d[15] = 0.f;
+    if (JAC) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) s_jac[tid * 9 + e] = J[e];
+    }
+    *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(o.A, o.B, o.C);
+    if (depth_keys) depth_keys[m] = gsr_depth_key(o.depth, key_bias, key_max);
+  }
+  __syncthreads();
+  const int nrows = (int)min((int64_t)256, count - m0);
+  float4* out4 = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m0);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = it * 256 + tid, row = e >> 2, part = e & 3;
+    if (row < nrows) {
+      const float* d = s_out + row * OP + 4 * part;
+      out4[e] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+  }
+  if (JAC) {
+    float* jout = jac + 9 * m0;
+    for (int e = tid; e < nrows * 9; e += 256) jout[e] = s_jac[e];
+  }
+#else
+  if (!valid) return;
   float4* r = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
   r[0] = make_float4(o.u, o.v, o.A, o.B);
   r[1] = make_float4(o.C, o.opacity, o.depth, col[0]);
@@ -226,6 +337,7 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
 #pragma unroll
     for (int e = 0; e < 9; ++e) jac[9 * m + e] = J[e];
   }
+#endif
 }
 
 // The (M,6) + (M,) + (M,C) tensors of the three-call form packed into the same rows (render_projected takes them from the

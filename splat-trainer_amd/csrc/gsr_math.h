@@ -35,10 +35,17 @@ GSR_HD GsrCam gsr_load_cam(const float* T, const float* proj) {
   return c;
 }
 
+// Rounding is PINNED in the forward projection (gsr_to_camera, gsr_quat_to_rot, gsr_project_one): every fused
+// multiply-add is written out and nothing else may be contracted.  The projection is inlined into several kernels (K1,
+// stand-alone K2, fused K2 + K3 with and without the saved Jacobian) that must return the same bits -- a frame's image,
+// and with it the controller scores and densification masks, must not depend on which call form or mode rendered it.
 GSR_HD void gsr_to_camera(const GsrCam& c, float px, float py, float pz, float& x, float& y, float& z) {
-  x = c.R[0] * px + c.R[1] * py + c.R[2] * pz + c.t[0];
-  y = c.R[3] * px + c.R[4] * py + c.R[5] * pz + c.t[1];
-  z = c.R[6] * px + c.R[7] * py + c.R[8] * pz + c.t[2];
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  x = fmaf(c.R[0], px, fmaf(c.R[1], py, fmaf(c.R[2], pz, c.t[0])));
+  y = fmaf(c.R[3], px, fmaf(c.R[4], py, fmaf(c.R[5], pz, c.t[1])));
+  z = fmaf(c.R[6], px, fmaf(c.R[7], py, fmaf(c.R[8], pz, c.t[2])));
 }
 
 // centre-in-frustum test (K1).  The expanded image bound keeps x/z, y/z bounded for K2.
@@ -53,63 +60,69 @@ GSR_HD bool gsr_in_view(const GsrCam& c, float px, float py, float pz, int W, in
 }
 
 GSR_HD void gsr_quat_to_rot(const float qn[4], float Rq[9]) {   // xyzw, already normalised
-  float x = qn[0], y = qn[1], z = qn[2], w = qn[3];
-  Rq[0] = 1.f - 2.f * (y * y + z * z); Rq[1] = 2.f * (x * y - w * z);       Rq[2] = 2.f * (x * z + w * y);
-  Rq[3] = 2.f * (x * y + w * z);       Rq[4] = 1.f - 2.f * (x * x + z * z); Rq[5] = 2.f * (y * z - w * x);
-  Rq[6] = 2.f * (x * z - w * y);       Rq[7] = 2.f * (y * z + w * x);       Rq[8] = 1.f - 2.f * (x * x + y * y);
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const float x = qn[0], y = qn[1], z = qn[2], w = qn[3];
+  Rq[0] = fmaf(-2.f, fmaf(y, y, z * z), 1.f); Rq[1] = 2.f * fmaf(x, y, -(w * z));       Rq[2] = 2.f * fmaf(x, z, w * y);
+  Rq[3] = 2.f * fmaf(x, y, w * z);            Rq[4] = fmaf(-2.f, fmaf(x, x, z * z), 1.f); Rq[5] = 2.f * fmaf(y, z, -(w * x));
+  Rq[6] = 2.f * fmaf(x, z, -(w * y));         Rq[7] = 2.f * fmaf(y, z, w * x);           Rq[8] = fmaf(-2.f, fmaf(x, x, y * y), 1.f);
 }
 
 struct GsrProjected {
   float u, v, A, B, C, opacity, depth, s_major, s_minor;
 };
 
-// K2 forward for one splat.
+// K2 forward for one splat (rounding pinned, see gsr_to_camera).
 GSR_HD GsrProjected gsr_project_one(const GsrCam& c, const GsrRasterParams& rp, const float p[3],
                                     const float ls[3], const float q[4], float logit) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   GsrProjected o;
   float x, y, z;
   gsr_to_camera(c, p[0], p[1], p[2], x, y, z);
-  float iz = 1.f / z;
-  o.u = c.fx * x * iz + c.cx;
-  o.v = c.fy * y * iz + c.cy;
+  const float iz = 1.f / z;
+  o.u = fmaf(c.fx * x, iz, c.cx);
+  o.v = fmaf(c.fy * y, iz, c.cy);
   o.depth = z;
 
   float qn[4];
-  float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float inv = 1.f / sqrtf(fmaf(q[0], q[0], fmaf(q[1], q[1], fmaf(q[2], q[2], q[3] * q[3]))));
   for (int i = 0; i < 4; ++i) qn[i] = q[i] * inv;
   float Rq[9];
   gsr_quat_to_rot(qn, Rq);
-  float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
+  const float s[3] = {expf(ls[0]), expf(ls[1]), expf(ls[2])};
 
   // Wm = J * R_cw  (2x3)
-  float j00 = c.fx * iz, j02 = -c.fx * x * iz * iz, j11 = c.fy * iz, j12 = -c.fy * y * iz * iz;
+  const float j00 = c.fx * iz, j02 = -c.fx * x * iz * iz, j11 = c.fy * iz, j12 = -c.fy * y * iz * iz;
   float Wm[6];
   for (int k = 0; k < 3; ++k) {
-    Wm[k]     = j00 * c.R[k]     + j02 * c.R[6 + k];
-    Wm[3 + k] = j11 * c.R[3 + k] + j12 * c.R[6 + k];
+    Wm[k]     = fmaf(j00, c.R[k], j02 * c.R[6 + k]);
+    Wm[3 + k] = fmaf(j11, c.R[3 + k], j12 * c.R[6 + k]);
   }
   // Tm = Wm * (Rq diag(s))  (2x3)
   float Tm[6];
   for (int cc = 0; cc < 3; ++cc) {
-    float m0 = Rq[cc] * s[cc], m1 = Rq[3 + cc] * s[cc], m2 = Rq[6 + cc] * s[cc];
-    Tm[cc]     = Wm[0] * m0 + Wm[1] * m1 + Wm[2] * m2;
-    Tm[3 + cc] = Wm[3] * m0 + Wm[4] * m1 + Wm[5] * m2;
+    const float m0 = Rq[cc] * s[cc], m1 = Rq[3 + cc] * s[cc], m2 = Rq[6 + cc] * s[cc];
+    Tm[cc]     = fmaf(Wm[0], m0, fmaf(Wm[1], m1, Wm[2] * m2));
+    Tm[3 + cc] = fmaf(Wm[3], m0, fmaf(Wm[4], m1, Wm[5] * m2));
   }
-  float a0 = Tm[0] * Tm[0] + Tm[1] * Tm[1] + Tm[2] * Tm[2];
-  float b0 = Tm[0] * Tm[3] + Tm[1] * Tm[4] + Tm[2] * Tm[5];
-  float c0 = Tm[3] * Tm[3] + Tm[4] * Tm[4] + Tm[5] * Tm[5];
-  float a = a0 + rp.blur, b = b0, cc2 = c0 + rp.blur;
-  float det = a * cc2 - b * b;
-  float idet = 1.f / det;
+  const float a0 = fmaf(Tm[0], Tm[0], fmaf(Tm[1], Tm[1], Tm[2] * Tm[2]));
+  const float b0 = fmaf(Tm[0], Tm[3], fmaf(Tm[1], Tm[4], Tm[2] * Tm[5]));
+  const float c0 = fmaf(Tm[3], Tm[3], fmaf(Tm[4], Tm[4], Tm[5] * Tm[5]));
+  const float a = a0 + rp.blur, b = b0, cc2 = c0 + rp.blur;
+  const float det = fmaf(a, cc2, -(b * b));
+  const float idet = 1.f / det;
   o.A = cc2 * idet; o.B = -b * idet; o.C = a * idet;
   float op = 1.f / (1.f + expf(-logit));
   if (rp.antialias) {
-    float rho = (a0 * c0 - b0 * b0) * idet;
+    const float rho = fmaf(a0, c0, -(b0 * b0)) * idet;
     op *= sqrtf(fmaxf(rho, 0.f));
   }
   o.opacity = op;
-  float mid = 0.5f * (a + cc2);
-  float rad = sqrtf(fmaxf(mid * mid - det, 0.f));
+  const float mid = 0.5f * (a + cc2);
+  const float rad = sqrtf(fmaxf(fmaf(mid, mid, -det), 0.f));
   o.s_major = sqrtf(mid + rad);
   o.s_minor = sqrtf(fmaxf(mid - rad, 0.f));
   return o;
@@ -309,6 +322,36 @@ GSR_HD void gsr_sh_basis_grad(float x, float y, float z, float* dx, float* dy, f
       dx[14] = 2.f * e5 * xz;                dy[14] = -2.f * e5 * yz;                   dz[14] = e5 * (xx - yy);
       dx[15] = e6 * (3.f * xx - 3.f * yy);   dy[15] = -6.f * e6 * xy;                   dz[15] = 0.f;
     }
+  }
+}
+
+// The same partial derivatives, one basis function at a time (k is a compile-time constant after unrolling, the switch
+// folds away): lets a caller consume dY_k right where it forms it instead of holding all 3K values in registers.
+template <int K>
+GSR_HD void gsr_sh_basis_grad_at(int k, float x, float y, float z, float& ax, float& ay, float& az) {
+  const float c0 = 1.0925484305920792f, c1 = -1.0925484305920792f, c2 = 0.31539156525252005f,
+              c3 = -1.0925484305920792f, c4 = 0.5462742152960396f;
+  const float e0 = -0.5900435899266435f, e1 = 2.890611442640554f, e2 = -0.4570457994644658f,
+              e3 = 0.3731763325901154f, e4 = -0.4570457994644658f, e5 = 1.445305721320277f,
+              e6 = -0.5900435899266435f;
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+  switch (k) {
+    case 1: ax = 0.f; ay = -GSR_SH_C1; az = 0.f; break;
+    case 2: ax = 0.f; ay = 0.f; az = GSR_SH_C1; break;
+    case 3: ax = -GSR_SH_C1; ay = 0.f; az = 0.f; break;
+    case 4: ax = c0 * y; ay = c0 * x; az = 0.f; break;
+    case 5: ax = 0.f; ay = c1 * z; az = c1 * y; break;
+    case 6: ax = -2.f * c2 * x; ay = -2.f * c2 * y; az = 4.f * c2 * z; break;
+    case 7: ax = c3 * z; ay = 0.f; az = c3 * x; break;
+    case 8: ax = 2.f * c4 * x; ay = -2.f * c4 * y; az = 0.f; break;
+    case 9: ax = 6.f * e0 * xy; ay = e0 * (3.f * xx - 3.f * yy); az = 0.f; break;
+    case 10: ax = e1 * yz; ay = e1 * xz; az = e1 * xy; break;
+    case 11: ax = -2.f * e2 * xy; ay = e2 * (4.f * zz - xx - 3.f * yy); az = 8.f * e2 * yz; break;
+    case 12: ax = -6.f * e3 * xz; ay = -6.f * e3 * yz; az = e3 * (6.f * zz - 3.f * xx - 3.f * yy); break;
+    case 13: ax = e4 * (4.f * zz - 3.f * xx - yy); ay = -2.f * e4 * xy; az = 8.f * e4 * xz; break;
+    case 14: ax = 2.f * e5 * xz; ay = -2.f * e5 * yz; az = e5 * (xx - yy); break;
+    case 15: ax = e6 * (3.f * xx - 3.f * yy); ay = -6.f * e6 * xy; az = 0.f; break;
+    default: ax = ay = az = 0.f; break;
   }
 }
 

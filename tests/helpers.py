@@ -28,20 +28,49 @@ def frac_above(a: torch.Tensor, b: torch.Tensor, tol: float) -> float:
 
 
 # Observed parity numbers of this session: (label, key, max error relative to the tensor's max magnitude, entries above
-# tol, entries).  tests/conftest.py prints the table at the end of the run and writes it to gpurun_out/parity_observed.txt
-# so that every bound asserted in the tests can be read against what was actually measured.
+# tol, entries, tol, entries violating the PER-ENTRY criterion).  tests/conftest.py prints the table at the end of the run
+# and writes it to gpurun_out/parity_observed.txt so that every bound asserted in the tests can be read against what was
+# actually measured.
 PARITY_LOG = []
 
 
+def per_entry_violations(a_: torch.Tensor, b_: torch.Tensor, tol: float) -> int:
+  """Entries with |a - b| > tol |b| + 1e-2 tol max|b|: the error relative to the ENTRY itself (a gradient row a hundred
+  times smaller than the tensor's largest must still be right to ``tol`` of its own size), with an absolute floor two
+  orders below the tensor-relative criterion for entries that are (nearly) zero."""
+  if not a_.numel():
+    return 0
+  scale = max(b_.abs().max().item(), 1e-30)
+  return int(((a_ - b_).abs() > tol * b_.abs() + 1e-2 * tol * scale).sum().item())
+
+
 def observe(label: str, key: str, a: torch.Tensor, b: torch.Tensor, tol: float):
-  """Records and returns (max rel err, fraction of entries above tol)."""
+  """Records and returns (max rel err, fraction of entries above tol) -- both relative to the tensor's largest magnitude;
+  the per-entry figure (``per_entry_violations``) is logged next to them."""
   a_, b_ = a.detach().double().cpu(), b.detach().double().cpu()
   scale = max(b_.abs().max().item(), 1e-30)
   err = (a_ - b_).abs() / scale
   worst = err.max().item() if err.numel() else 0.0
   above = int((err > tol).sum().item())
-  PARITY_LOG.append((label, key, worst, above, err.numel(), tol))
+  PARITY_LOG.append((label, key, worst, above, err.numel(), tol, per_entry_violations(a_, b_, tol)))
   return worst, above / max(err.numel(), 1)
+
+
+# A pixel within fp32 rounding of a discrete contribute / skip boundary (q = 9, alpha = 1/255, T = 1e-4) takes the other
+# branch than the fp64 oracle and moves that pixel -- and the per-point sums and gradients of the one or two splats
+# involved -- by one minimal contribution.  WHICH scenes show such a flip depends on every rounding upstream (it moved
+# when the forward projection's fma pattern was pinned in round 3), so the tests state the rule, not a list of scenes:
+# every entry within tol, or the exceptions are isolated -- few (a share of the tensor, or 3 entries of a small one) and
+# small (1e-2 of the tensor's largest magnitude).
+FLIP_SHARE, FLIP_SIZE = 4e-3, 1e-2
+
+
+def clean_or_isolated_flip(label: str, key: str, a: torch.Tensor, b: torch.Tensor, tol: float) -> bool:
+  """Asserts the rule above for one tensor; returns True when a flip was seen."""
+  worst, frac = observe(label, key, a, b, tol)
+  n = a.numel()
+  assert frac * n <= max(3.0, FLIP_SHARE * n) + 0.5 and worst < max(tol, FLIP_SIZE), (label, key, frac, worst)
+  return frac > 0
 
 
 GRAD_KEYS = ("d_position", "d_log_scaling", "d_rotation", "d_alpha_logit", "d_feature")

@@ -43,7 +43,10 @@ def test_config1_10k_256_matches_oracle():
   g, cam = synthetic.scene_a(10_000, 256, 256, sh_degree=0, seed=0)
   hip = hip_render_and_grads(g, cam, CFG, use_sh=True)
   orc = oracle_render_and_grads(g, cam, CFG, use_sh=True)
-  _compare(hip, orc)
+  # 2.8e4 (tile, splat) pairs, 1e6 contributing (pixel, splat) pairs: an isolated boundary flip may show (observed in
+  # round 3: 2 of 196 608 image entries, 2.5e-4); allowances = the share / size rule of the full-size configs
+  compare_to_oracle("test_config1_10k_256_matches_oracle", hip, orc, TOL, pixel_flips=5e-5, point_flips=3e-4,
+                    worst_pixel=1e-2, worst_point=1e-2)
   mse = ((hip["image"].cpu() - orc["image"]) ** 2).mean().item()
   assert mse < 1e-10                       # PSNR vs oracle > 100 dB
   assert abs(hip["num_overlaps"]) > 0
@@ -500,6 +503,50 @@ def test_speculative_emit_and_early_colours_do_not_change_results():
   # the geometry gradients come out of differently fused kernels in the two forms (K2 backward alone vs K2 backward +
   # the colour gradient's position term in one sweep): same arithmetic, the compiler may contract other fma pairs
   assert rel_err(gd.position.grad, first_large["d_position"]) < 1e-6
+
+
+def test_visibility_read_before_backward_is_what_backward_delivers():
+  """points.visibility comes out of the backward pass's own reduction (a column of the packed gradient rows); a reader
+  that comes before loss.backward() -- reg_loss on points.visible, mlp_scene.py:268-288 -- triggers the stand-alone
+  forward-side reduction instead.  Same partials summed in the same order: the same bits, in both call forms, and
+  reading early does not change anything else."""
+  g, cam = small_scene(3000, 160, 120, sh_degree=1, seed=5, sigma_px=3.0)
+  camd = cam.to("cuda")
+
+  def leaves():
+    return sta.Gaussians3D(*(t.clone().cuda().requires_grad_(True) for t in
+                             (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+
+  def one_call(early):
+    gd = leaves()
+    r = sta.render_gaussians(gd, camd, CFG, use_sh=True)
+    before = r.points.visibility.clone() if early else None
+    ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+    return before, r.points.visibility.clone(), r.points.prune_cost.clone(), gd.position.grad.clone()
+
+  def three_calls(early):
+    gd = leaves()
+    g2d, depth, idx = sta.project_to_image(gd, camd, CFG)
+    feats = sta.evaluate_sh_at(gd.feature, gd.position, idx, camd.camera_position)
+    r = sta.render_projected(idx, g2d, feats, depth, camd, CFG)
+    before = r.points.visible.visibility.clone() if early else None        # the reference's access pattern
+    ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+    return before, r.points.visibility.clone(), r.points.prune_cost.clone(), gd.position.grad.clone()
+
+  for form in (one_call, three_calls):
+    b_early, a_early, p_early, g_early = form(True)
+    _, a_late, p_late, g_late = form(False)
+    assert a_late.abs().max() > 0
+    assert torch.equal(a_early, a_late) and torch.equal(p_early, p_late) and torch.equal(g_early, g_late)
+    full = b_early if form is one_call else None
+    if full is not None:
+      assert torch.equal(full, a_late)
+    else:
+      assert torch.equal(b_early, a_late[a_late > 0])
+  # without gradients the forward pass reduces at once
+  with torch.no_grad():
+    r = sta.render_gaussians(leaves(), camd, CFG, use_sh=True)
+  assert torch.equal(r.points.visibility, one_call(False)[1])
 
 
 def test_overlap_count_overflow_is_reported_not_wrapped():

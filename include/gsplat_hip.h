@@ -169,17 +169,20 @@ int gsr_project_sh_forward(const float* position, const float* log_scaling, cons
                            float* jacobian_out, const uint32_t* count_dev, uint32_t* depth_keys_out,
                            uint32_t depth_key_bias, uint32_t depth_key_max, void* stream);
 /* Backward of the geometry half from the packed gradient rows of gsr_reduce_gradients, one sequential sweep in splat
- * order: K2 backward into rows ``indexes`` of the N-sized gradient tensors (written, or added to when accumulate = 1; all
- * four or none -- d_position NULL skips the geometry), plus the position term of the colour gradient when ``jacobian``
- * [M,9] is given.  dL_dgaussians2d_extra [M,6] / dL_ddepth [M] (may be NULL): gradients that reached gaussians2d /
- * depth from outside the rasterizer.  The rows' scalar columns are copied out where asked: d_colors_out [M,3] (input of
- * the gsr_sh_backward* calls), prune_cost_out / split_score_out / visibility_out [M]. */
+ * order: K2 backward into the N-sized gradient tensors (all four or none -- d_position NULL skips the geometry), plus
+ * the position term of the colour gradient when ``jacobian`` [M,9] is given.  mode 0: rows ``indexes`` are written (the
+ * others untouched: pass zeros); 1: added to ("+="); 2: EVERY scene row is written, zeros where the camera saw nothing
+ * (no zero-fill by the caller, no read-modify-write) -- ``inverse`` [N] from gsr_inverse_map, or NULL when M == N.
+ * dL_dgaussians2d_extra [M,6] / dL_ddepth [M] (may be NULL): gradients that reached gaussians2d / depth from outside the
+ * rasterizer.  The rows' scalar columns are copied out where asked: d_colors_out [M,3] (input of the gsr_sh_backward*
+ * calls), prune_cost_out / split_score_out / visibility_out [M]. */
 int gsr_project_backward_rows(const float* position, const float* log_scaling, const float* rotation_xyzw,
-                              const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
-                              const float* projection, const GsrRasterParamsC* params_host, const float* grad_rows,
+                              const float* alpha_logit, const int64_t* indexes, int64_t M, const int32_t* inverse,
+                              int64_t N, const float* T_camera_world, const float* projection,
+                              const GsrRasterParamsC* params_host, const float* grad_rows,
                               const float* dL_dgaussians2d_extra, const float* dL_ddepth, const float* jacobian,
                               float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,
-                              int32_t accumulate, float* d_colors_out, float* prune_cost_out, float* split_score_out,
+                              int32_t mode, float* d_colors_out, float* prune_cost_out, float* split_score_out,
                               float* visibility_out, void* stream);
 
 /* ---- K4 tile overlap count / key emit, tile ranges  (render_projected, binning) ------------------------- */

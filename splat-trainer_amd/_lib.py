@@ -72,8 +72,8 @@ PROTOTYPES = {
     "gsr_depth_keys": (C.c_int, [_p, _i64, _u32, _u32, _p, _p]),
     "gsr_project_sh_forward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _pp, _p, _p, _p, _p, _p, _u32,
                                          _u32, _p]),
-    "gsr_project_backward_rows": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _p, _p, _i32,
-                                            _p, _p, _p, _p, _p]),
+    "gsr_project_backward_rows": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _p,
+                                            _p, _i32, _p, _p, _p, _p, _p]),
     "gsr_pack_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
     "gsr_tile_count": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),
     "gsr_tile_emit": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p]),

@@ -368,17 +368,36 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
 // contiguous per-point outputs (prune_cost, split_score, visibility) and the colour gradient (M,3) the SH coefficient
 // backward consumes.  ``dg2d_extra`` / ``ddepth``: gradients that reached gaussians2d / depth from outside the
 // rasterizer (a regularizer on points.opacity / points.depths, mlp_scene.py:268-288); may be NULL.
-template <bool ACC>
+// MODE 0: rows ``idx`` of the gradient tensors are written (the others untouched); 1: added to ("+=");
+// 2: EVERY scene row is written -- zeros where the camera saw nothing -- so the caller needs neither a zero-filled buffer
+// nor a read-modify-write (thread per scene row, ``inv`` = row -> visible rank or -1, NULL when every row is visible).
+template <int MODE>
 __global__ __launch_bounds__(256) void project_bwd_rows_kernel(
     const float* __restrict__ pos, const float* __restrict__ ls, const float* __restrict__ rot,
-    const float* __restrict__ logit, const int64_t* __restrict__ idx, int64_t M, const float* __restrict__ Tcw,
-    const float* __restrict__ proj, GsrRasterParams rp, const float* __restrict__ grows,
-    const float* __restrict__ dg2d_extra, const float* __restrict__ ddepth, const float* __restrict__ jac,
-    float* __restrict__ dpos, float* __restrict__ dls, float* __restrict__ drot, float* __restrict__ dlogit,
-    float* __restrict__ dcol_out, float* __restrict__ prune_out, float* __restrict__ split_out,
-    float* __restrict__ vis_out) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+    const float* __restrict__ logit, const int64_t* __restrict__ idx, int64_t M, const int32_t* __restrict__ inv,
+    int64_t N, const float* __restrict__ Tcw, const float* __restrict__ proj, GsrRasterParams rp,
+    const float* __restrict__ grows, const float* __restrict__ dg2d_extra, const float* __restrict__ ddepth,
+    const float* __restrict__ jac, float* __restrict__ dpos, float* __restrict__ dls, float* __restrict__ drot,
+    float* __restrict__ dlogit, float* __restrict__ dcol_out, float* __restrict__ prune_out,
+    float* __restrict__ split_out, float* __restrict__ vis_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t m, i;
+  if (MODE == 2) {
+    if (t >= N) return;
+    i = t;
+    m = inv ? (int64_t)inv[t] : t;
+    if (m < 0) {                                              // not seen by this camera: zero gradient
+      dpos[3 * i] = 0.f; dpos[3 * i + 1] = 0.f; dpos[3 * i + 2] = 0.f;
+      dls[3 * i] = 0.f; dls[3 * i + 1] = 0.f; dls[3 * i + 2] = 0.f;
+      *reinterpret_cast<float4*>(drot + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      dlogit[i] = 0.f;
+      return;
+    }
+  } else {
+    if (t >= M) return;
+    m = t;
+    i = dpos ? idx[m] : 0;
+  }
   const float4* gr = reinterpret_cast<const float4*>(grows + (int64_t)GSR_ROW_FLOATS * m);
   const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
   if (prune_out) prune_out[m] = g1.z;
@@ -387,7 +406,6 @@ __global__ __launch_bounds__(256) void project_bwd_rows_kernel(
   if (dcol_out) { dcol_out[3 * m] = g2.x; dcol_out[3 * m + 1] = g2.y; dcol_out[3 * m + 2] = g2.z; }
   if (!dpos) return;
   const GsrCam cam = gsr_load_cam(Tcw, proj);
-  const int64_t i = idx[m];
   float p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
   float s[3] = {ls[3 * i], ls[3 * i + 1], ls[3 * i + 2]};
   const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * i);
@@ -405,6 +423,7 @@ __global__ __launch_bounds__(256) void project_bwd_rows_kernel(
     gsr_jac_apply(g3, jac + 9 * m, pj);
     o.dp[0] += pj[0]; o.dp[1] += pj[1]; o.dp[2] += pj[2];
   }
+  constexpr bool ACC = MODE == 1;
   float4 r = make_float4(o.dq[0], o.dq[1], o.dq[2], o.dq[3]);
   if (ACC) {
     const float4 old = *reinterpret_cast<const float4*>(drot + 4 * i);
@@ -768,34 +787,33 @@ int gsr_pack_rows(const float* gaussians2d, const float* depth, const float* fea
 }
 
 int gsr_project_backward_rows(const float* position, const float* log_scaling, const float* rotation_xyzw,
-                              const float* alpha_logit, const int64_t* indexes, int64_t M, const float* T_camera_world,
-                              const float* projection, const GsrRasterParamsC* params_host, const float* grad_rows,
+                              const float* alpha_logit, const int64_t* indexes, int64_t M, const int32_t* inverse,
+                              int64_t N, const float* T_camera_world, const float* projection,
+                              const GsrRasterParamsC* params_host, const float* grad_rows,
                               const float* dL_dgaussians2d_extra, const float* dL_ddepth, const float* jacobian,
                               float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,
-                              int32_t accumulate, float* d_colors_out, float* prune_cost_out, float* split_score_out,
+                              int32_t mode, float* d_colors_out, float* prune_cost_out, float* split_score_out,
                               float* visibility_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
-  if (M == 0) return GSR_OK;
-  if (!grad_rows) return GSR_ERR_INVALID_ARGUMENT;
+  if (M < 0 || N < 0 || M > N || !params_host || mode < 0 || mode > 2) return GSR_ERR_INVALID_ARGUMENT;
   const bool geom = d_position != nullptr;
-  if (geom && (!position || !log_scaling || !rotation_xyzw || !alpha_logit || !indexes || !T_camera_world ||
-               !projection || !d_log_scaling || !d_rotation || !d_alpha_logit))
+  if (geom && (!position || !log_scaling || !rotation_xyzw || !alpha_logit || !T_camera_world || !projection ||
+               !d_log_scaling || !d_rotation || !d_alpha_logit || (M > 0 && !indexes)))
     return GSR_ERR_INVALID_ARGUMENT;
-  const unsigned g = grid_for(M, 256);
+  if (mode == 2 && (!geom || (!inverse && M != N))) return GSR_ERR_INVALID_ARGUMENT;   // identity map only when all rows are visible
+  if (mode != 2 && M == 0) return GSR_OK;
+  if (mode == 2 && N == 0) return GSR_OK;
+  if (M > 0 && !grad_rows) return GSR_ERR_INVALID_ARGUMENT;
   const GsrRasterParams rp = to_params(params_host);
-  if (accumulate)
-    project_bwd_rows_kernel<true><<<g, 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
-                                                        T_camera_world, projection, rp, grad_rows, dL_dgaussians2d_extra,
-                                                        dL_ddepth, jacobian, d_position, d_log_scaling, d_rotation,
-                                                        d_alpha_logit, d_colors_out, prune_cost_out, split_score_out,
-                                                        visibility_out);
-  else
-    project_bwd_rows_kernel<false><<<g, 256, 0, stream>>>(position, log_scaling, rotation_xyzw, alpha_logit, indexes, M,
-                                                         T_camera_world, projection, rp, grad_rows, dL_dgaussians2d_extra,
-                                                         dL_ddepth, jacobian, d_position, d_log_scaling, d_rotation,
-                                                         d_alpha_logit, d_colors_out, prune_cost_out, split_score_out,
-                                                         visibility_out);
+#define GSR_LAUNCH_PBR(MODE, COUNT)                                                                                      \
+  project_bwd_rows_kernel<MODE><<<grid_for(COUNT, 256), 256, 0, stream>>>(                                               \
+      position, log_scaling, rotation_xyzw, alpha_logit, indexes, M, inverse, N, T_camera_world, projection, rp,         \
+      grad_rows, dL_dgaussians2d_extra, dL_ddepth, jacobian, d_position, d_log_scaling, d_rotation, d_alpha_logit,       \
+      d_colors_out, prune_cost_out, split_score_out, visibility_out)
+  if (mode == 2) GSR_LAUNCH_PBR(2, N);
+  else if (mode == 1) GSR_LAUNCH_PBR(1, M);
+  else GSR_LAUNCH_PBR(0, M);
+#undef GSR_LAUNCH_PBR
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

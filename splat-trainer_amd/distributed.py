@@ -71,19 +71,23 @@ class GradBucket:
       p.grad = v
 
   def zero(self, except_views: Sequence[int] = ()):
-    """Zero-fills the buffer; ``except_views`` lists parameter slots to leave alone (e.g. the feature gradient when
-    ``GradOut.feature_uninitialized`` lets the SH backward overwrite it)."""
+    """Zero-fills the buffer; ``except_views`` lists parameter slots to leave alone (their first backward pass of the
+    batch overwrites every row: ``GradOut.geometry_uninitialized`` / ``feature_uninitialized``).  The alignment padding
+    between slots is zero from construction and never written, so it is only filled through when that saves a launch."""
     if not except_views:
       self.flat.zero_()
       return
-    cuts = sorted((self._starts[i], self._starts[i] + self.params[i].numel()) for i in except_views)
-    at = 0
-    for lo, hi in cuts:
-      if lo > at:
-        self.flat[at:lo].zero_()
-      at = hi
-    if at < self._used:
-      self.flat[at:].zero_()
+    keep = set(except_views)
+    todo = [(0, self.extra.numel())] if self.extra.numel() else []
+    todo += [(o, o + p.numel()) for i, (p, o) in enumerate(zip(self.params, self._starts)) if i not in keep]
+    merged = []
+    for lo, hi in sorted(todo):
+      if merged and lo - merged[-1][1] < 64:          # neighbours separated by padding only: one fill
+        merged[-1][1] = hi
+      else:
+        merged.append([lo, hi])
+    for lo, hi in merged:
+      self.flat[lo:hi].zero_()
 
   def all_reduce(self, group=None, mode: str = "all_reduce", async_op: bool = False, even_single: bool = False):
     """Sums the buffer over the ranks.  ``async_op=True`` (all_reduce mode only) returns the work handle instead of
@@ -372,10 +376,15 @@ class CameraShardedStep:
 
   def __init__(self, params: Sequence[torch.Tensor], world_size: int, rank: int, group=None,
                mode: str = DEFAULT_COLLECTIVE, with_stats: bool = True, packed: bool = False,
-               exchange_when_single: bool = False):
+               exchange_when_single: bool = False, fused_grad_out: bool = True):
     """``packed``: exchange rows padded to the batch's largest visible count instead of the dense per-point block
     (needs a count exchange + host sync per batch).  ``exchange_when_single``: run the exchange even with one rank
-    (tests: packing, the collectives on a one-rank group, rebuild and replay on a single GPU)."""
+    (tests: packing, the collectives on a one-rank group, rebuild and replay on a single GPU).
+    ``fused_grad_out`` (default): ``render_backward`` hands ``grad_out`` on to ``render_gaussians`` /
+    ``project_to_image``, whose first backward pass of a batch initialises the gradient buffers itself (every row
+    written, zeros where its camera saw nothing): no zero-fill per batch.  False: the buffers are zero-filled per batch
+    and the callback may accumulate into ``param.grad`` any way it likes."""
+    self.fused = bool(fused_grad_out)
     from .renderer import GradOut
     from .sh import ShFactorCollector
     self.params = list(params)
@@ -415,16 +424,24 @@ class CameraShardedStep:
     light = point_state is not None
     mine = shard_cameras(len(cameras), self.rank, self.world)
     dense = self.factor and light and not self.packed
-    if self.factor:
+    if self.fused:
+      # Only the two sum columns are zero-filled: the first backward pass of the batch overwrites every row of the four
+      # geometry gradients (and, when it is formed here, of the feature gradient) -- zeros where its camera saw nothing
+      self.bucket.zero(except_views=(0, 1, 2, 3) if self.factor else (0, 1, 2, 3, 4))
+      self.grad_out.geometry_uninitialized = True
+      if not self.factor:
+        self.grad_out.feature_uninitialized = True
+    else:
       self.bucket.zero()
-    else:                                     # the first SH backward of the batch overwrites the feature gradient
-      self.bucket.zero(except_views=(4,))
-      self.grad_out.feature_uninitialized = True
     local = []
     if light and self.exchange and not dense:
       self.scale_max.zero_()
     for j in mine:
       r = render_backward(j, cameras[j], self.grad_out, self.collector)
+      if self.grad_out.geometry_uninitialized:
+        raise RuntimeError("render_backward did not route grad_out into the renderer's backward pass (the gradient "
+                           "buffers of this batch are uninitialised): pass grad_out on, or construct "
+                           "CameraShardedStep(fused_grad_out=False)")
       if dense:                               # sums ride in the all-reduce; scores + scale go into the camera's block
         local.append(dict(camera=j, idx=r.points.idx, split_score=r.points.split_score, prune_cost=r.points.prune_cost,
                           screen_scale=r.points.screen_scale, visibility=r.points.visibility))
@@ -439,6 +456,10 @@ class CameraShardedStep:
       self.bucket.extra[:N].index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
       if self.with_stats:
         local.append(point_stats_of(j, r.points))
+    if self.grad_out.geometry_uninitialized:   # this rank had no camera in the batch: its share of the sum is zero
+      self.grad_out.geometry_uninitialized = False
+      for v in self.bucket.views[:4]:
+        v.zero_()
     if not self.exchange:
       return [] if light else local
     if dense:

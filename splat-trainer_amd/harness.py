@@ -140,17 +140,15 @@ class MiniTrainer:
     """The parameters' ``.grad`` tensors as the accumulation target of the backward kernels (renderer.GradOut): the
     reference sums the cameras of a batch into ``.grad`` through autograd (trainer.py:500-514, zero_grad only in
     scene.step); here the kernels add their rows straight into the same tensors, which spares every camera the dense
-    N-sized temporaries and autograd's accumulate pass over them.  The coefficient gradient -- 48 of the 59 floats per
-    point -- is not even zero-filled: the first camera's SH backward overwrites it row for row."""
+    N-sized temporaries and autograd's accumulate pass over them.  Nothing is zero-filled: the first camera's backward
+    pass writes every row (zeros where it saw nothing), the later ones add."""
     grads = {}
     for n in PARAM_NAMES:
       p = self.points.tensors[n]
       if p.grad is None or p.grad.shape != p.shape:
         p.grad = torch.empty_like(p)
-      if n != "feature":
-        p.grad.zero_()
       grads[n] = p.grad
-    return GradOut(feature_uninitialized=True, **grads)
+    return GradOut(feature_uninitialized=True, geometry_uninitialized=True, **grads)
 
   def training_step(self) -> float:
     """trainer.py:531-545: evaluate_backward_with over the batch, then the optimizer step."""

@@ -157,13 +157,23 @@ class GradOut:
   ``feature_uninitialized = True`` tells the next SH backward that ``feature`` (by far the largest buffer, 3K of the
   3K+11 floats per splat) holds nothing worth keeping: it is then overwritten row for row -- zeros where the camera saw
   nothing -- instead of zero-filled by the caller and added to, and the flag is cleared.  Set it before the first
-  camera of a batch and skip ``feature`` in the zero-fill."""
+  camera of a batch and skip ``feature`` in the zero-fill.  ``geometry_uninitialized = True`` says the same of the four
+  geometry buffers (position, log_scaling, rotation, alpha_logit): the next backward pass writes every row of them --
+  zeros where its camera saw nothing -- and clears the flag, so a batch needs no zero-fill of its gradient buffers and
+  its first camera no read-modify-write."""
 
   def __init__(self, position=None, log_scaling=None, rotation=None, alpha_logit=None, feature=None,
-               feature_uninitialized: bool = False):
+               feature_uninitialized: bool = False, geometry_uninitialized: bool = False):
     self.position, self.log_scaling, self.rotation = position, log_scaling, rotation
     self.alpha_logit, self.feature = alpha_logit, feature
     self.feature_uninitialized = feature_uninitialized
+    self.geometry_uninitialized = geometry_uninitialized
+
+  def take_geometry_uninitialized(self) -> bool:
+    """True once per batch when the caller declared the four geometry buffers uninitialised: the backward pass that
+    sees it must leave every row defined (overwrite all of them, or zero-fill before adding)."""
+    flag, self.geometry_uninitialized = self.geometry_uninitialized, False
+    return flag
 
   def _check(self, name, like):
     t = getattr(self, name)
@@ -228,6 +238,9 @@ class _ProjectFn(torch.autograd.Function):
     if go is not None:
       d_pos, d_ls = go._check("position", pos), go._check("log_scaling", ls)
       d_rot, d_al = go._check("rotation", rot), go._check("alpha_logit", al)
+      if go.take_geometry_uninitialized():
+        for t in (d_pos, d_ls, d_rot, d_al):
+          t.zero_()
     else:
       live = M > 0 and (d_g2d is not None or d_depth is not None)
       alloc = torch.empty_like if (M == N and live) else torch.zeros_like   # every row is written when nothing was culled
@@ -624,25 +637,41 @@ class _FrameFn(torch.autograd.Function):
     go, sh_out = ctx.grad_out, ctx.sh_out
     collector = sh_out if isinstance(sh_out, _sh.ShFactorCollector) else None
     nothing = (None,) * 13
+    # Geometry gradients: added to caller-owned buffers (mode 1), or every scene row written -- zeros where the camera saw
+    # nothing -- when the destination holds nothing worth keeping (fresh tensors for autograd, or buffers the caller
+    # declared uninitialised): no zero-fill and no read-modify-write (mode 2; mode 0 + zero-fill when the camera saw
+    # less than an eighth of the scene)
+    dense = N > 0 and (M == N or 8 * M >= N)
     if go is not None:
       d_pos, d_ls = go._check("position", pos), go._check("log_scaling", ls)
       d_rot, d_al = go._check("rotation", rot), go._check("alpha_logit", al)
+      mode = 1
+      if go.take_geometry_uninitialized():
+        mode = 2 if dense else 0
+        if not dense:
+          for t in (d_pos, d_ls, d_rot, d_al):
+            t.zero_()
     else:
-      alloc = torch.empty_like if (M == N and M > 0) else torch.zeros_like   # every row is written when nothing was culled
+      alloc = torch.empty_like if dense else torch.zeros_like
       d_pos, d_ls, d_rot, d_al = alloc(pos), alloc(ls), alloc(rot), alloc(al)
+      mode = 2 if dense else 0
     # the SH coefficient gradient: to the factor collector (data-parallel), into caller-owned buffers, or returned
     want_sh = collector is not None or sh_out is not None or ctx.needs_input_grad[4]
     d_sh = None
-    if M > 0:
-      live = st.O > 0 and d_image is not None
-      grows = _composite_backward_rows(st, d_image, dev)
+    inv = None
+    if M < N and N > 0 and dense:
+      inv = torch.empty(N, dtype=torch.int32, device=dev)        # scene row -> visible rank (shared with the SH backward)
+      _lib.check(lib.gsr_inverse_map(_ptr(indexes), M, N, _ptr(inv), _stream()), "gsr_inverse_map")
+    if M > 0 or mode == 2:
+      live = M > 0 and st.O > 0 and d_image is not None
+      grows = _composite_backward_rows(st, d_image, dev) if M > 0 else None
       dg = _f32c(d_g2d) if d_g2d is not None else None
       dd = _f32c(d_depth).reshape(-1) if d_depth is not None else None
       dcol = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_sh else None
-      _lib.check(lib.gsr_project_backward_rows(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M, _ptr(T),
-                                               _ptr(proj), C.byref(st.params), _ptr(grows), _ptr(dg), _ptr(dd),
-                                               _ptr(ctx.jac), _ptr(d_pos), _ptr(d_ls), _ptr(d_rot), _ptr(d_al),
-                                               1 if go is not None else 0, _ptr(dcol),
+      _lib.check(lib.gsr_project_backward_rows(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M,
+                                               _ptr(inv) if mode == 2 else None, N, _ptr(T), _ptr(proj),
+                                               C.byref(st.params), _ptr(grows), _ptr(dg), _ptr(dd), _ptr(ctx.jac),
+                                               _ptr(d_pos), _ptr(d_ls), _ptr(d_rot), _ptr(d_al), mode, _ptr(dcol),
                                                _ptr(st.prune_cost) if live else None,
                                                _ptr(st.split_score) if live else None, _ptr(_vis_out(st, live)),
                                                _stream()), "gsr_project_backward_rows")
@@ -654,12 +683,8 @@ class _FrameFn(torch.autograd.Function):
       owner = sh_out[2] if (sh_out is not None and len(sh_out) > 2) else None
       overwrite = sh_out is None or (owner is not None and owner.feature_uninitialized)
       d_sh = sh_out[0] if sh_out is not None else torch.empty(N, 3, K, dtype=torch.float32, device=dev)
-      if overwrite and N > 0 and (M == N or 8 * M >= N):
+      if overwrite and dense:
         # every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no read-modify-write
-        inv = None
-        if M < N:
-          inv = torch.empty(N, dtype=torch.int32, device=dev)
-          _lib.check(lib.gsr_inverse_map(_ptr(indexes), M, N, _ptr(inv), _stream()), "gsr_inverse_map")
         _lib.check(lib.gsr_sh_backward_dense(_ptr(dcol), _ptr(sh), _ptr(pos), _ptr(inv), M, N, K, _ptr(cam), None,
                                              _ptr(d_sh), None, _stream()), "gsr_sh_backward_dense")
       else:

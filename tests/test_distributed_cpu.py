@@ -174,7 +174,7 @@ def _stats_worker(rank, world, port, out_path, num_cameras):
   import splat_trainer_amd as sta
   from splat_trainer_amd.distributed import CameraShardedStep
   params = [torch.zeros(n, d, requires_grad=True) for d in (3, 3, 4, 1)] + [torch.zeros(n, 3, 4, requires_grad=True)]
-  dp = CameraShardedStep(params, world, rank, mode="all_reduce")
+  dp = CameraShardedStep(params, world, rank, mode="all_reduce", fused_grad_out=False)     # the stand-in render writes no gradients
 
   def fake_render(j, cam, grad_out, collector):
     d = _camera_stats(j, n)

@@ -38,8 +38,10 @@ extern "C" {
 #define GSR_ERR_UNSUPPORTED -4
 
 #define GSR_ROW_FLOATS 16      /* packed per-splat row, 64 bytes, splat order:  u v A B | C op depth f0 | f1 f2 0 0 | 0 0 0 0;
-                                  the gradient rows use the same pitch:  du dv dA dB | dC dop prune split | df0 df1 df2 vis | 0 0 0 0 */
-#define GSR_PARTIAL_FLOATS 12  /* per-(tile,splat) gradient partial: du dv dA dB | dC dop prune split | df0 df1 df2 - */
+                                  the gradient rows use the same pitch:  mx my mxx mxy | myy dop prune split | df0 df1 df2 vis | 0 0 0 0 */
+#define GSR_PARTIAL_FLOATS 12  /* per-(tile,splat) gradient partial: mx my mxx mxy | myy dop prune split | df0 df1 df2 -
+                                  (m* = moments of G dL/dG about the splat's mean; the per-splat sweep turns their sums into
+                                  du = A mx + B my, dv = B mx + C my, dA = -mxx/2, dB = -mxy, dC = -myy/2) */
 
 #ifndef GSR_HAVE_RASTER_PARAMS
 #define GSR_HAVE_RASTER_PARAMS
@@ -72,7 +74,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 17) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 18) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -179,8 +181,9 @@ int gsr_project_sh_forward(const float* position, const float* log_scaling, cons
 int gsr_project_backward_rows(const float* position, const float* log_scaling, const float* rotation_xyzw,
                               const float* alpha_logit, const int64_t* indexes, int64_t M, const int32_t* inverse,
                               int64_t N, const float* T_camera_world, const float* projection,
-                              const GsrRasterParamsC* params_host, const float* grad_rows,
-                              const float* dL_dgaussians2d_extra, const float* dL_ddepth, const float* jacobian,
+                              const GsrRasterParamsC* params_host, const float* rows /* the forward rows [M,16] */,
+                              const float* grad_rows, const float* dL_dgaussians2d_extra, const float* dL_ddepth,
+                              const float* jacobian,
                               float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,
                               int32_t mode, float* d_colors_out, float* prune_cost_out, float* split_score_out,
                               float* visibility_out, void* stream);
@@ -268,14 +271,16 @@ int gsr_composite_backward(const float* rows /* [M,16] */, const uint32_t* sorte
 int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
                           const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity, void* stream);
 /* grad_rows_out [M,16] indexed by splat, each row written whole (the one crossing of the depth-order permutation on the
- * backward side):  du dv dA dB | dC dop prune_cost split_score | df0 df1 df2 visibility | 0 0 0 0.  The visibility column
- * holds the same bits gsr_reduce_visibility returns. */
+ * backward side):  mx my mxx mxy | myy dop prune_cost split_score | df0 df1 df2 visibility | 0 0 0 0  (m*: the summed
+ * moments of GSR_PARTIAL_FLOATS; gsr_project_backward_rows / gsr_unpack_grad_rows turn them into d(u, v, A, B, C) with
+ * the conic of the forward row).  The visibility column holds the same bits gsr_reduce_visibility returns. */
 int gsr_reduce_gradients(const float* partial, const float* vis_partial, const uint32_t* offsets,
                          const uint32_t* count, const uint32_t* order, int64_t M, float* grad_rows_out, void* stream);
 /* The rows taken apart for the three-call form: d_gaussians2d [M,6], d_features [M,C]; prune_cost / split_score /
  * visibility [M] (each may be NULL). */
-int gsr_unpack_grad_rows(const float* grad_rows, int64_t M, int32_t C, float* d_gaussians2d, float* d_features,
-                         float* prune_cost_out, float* split_score_out, float* visibility_out, void* stream);
+int gsr_unpack_grad_rows(const float* rows /* the forward rows [M,16] */, const float* grad_rows, int64_t M, int32_t C,
+                         float* d_gaussians2d, float* d_features, float* prune_cost_out, float* split_score_out,
+                         float* visibility_out, void* stream);
 
 /* ---- loss stage next to the path: fused SSIM, replaces the CUDA-only fused_ssim package
  *      the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462; trainer/evaluation.py:7,42) ------------ */

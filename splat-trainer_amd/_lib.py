@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class GsrRasterParamsC(C.Structure):
@@ -73,7 +73,7 @@ PROTOTYPES = {
     "gsr_project_sh_forward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _pp, _p, _p, _p, _p, _p, _u32,
                                          _u32, _p]),
     "gsr_project_backward_rows": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _p,
-                                            _p, _i32, _p, _p, _p, _p, _p]),
+                                            _p, _p, _i32, _p, _p, _p, _p, _p]),
     "gsr_pack_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
     "gsr_tile_count": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),
     "gsr_tile_emit": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p]),
@@ -103,7 +103,7 @@ PROTOTYPES = {
     "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p]),
-    "gsr_unpack_grad_rows": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "gsr_unpack_grad_rows": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict
 // LDS in ascending id order (fixed association order -> bit-reproducible).
 // The per-splat sums leave as ONE packed 64-byte row per splat, written whole by its thread (a full line: no partial
 // write, no read-modify-write) at the splat's id -- the only crossing of the depth-order permutation on the backward
-// side:   du dv dA dB | dC dop prune split | df0 df1 df2 visibility | 0 0 0 0.
+// side:   mx my mxx mxy | myy dop prune split | df0 df1 df2 visibility | 0 0 0 0   (m*: moments of G dL/dG about the
+// mean, composite.hip K7; the sweep in splat order that reads the rows turns them into d(u, v, A, B, C)).
 // The visibility column is the sum of the forward pass's per-pair partials in the same id order reduce_vis_kernel uses
 // (same bits), so a frame that is back-propagated needs no separate visibility reduction.
 __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restrict__ partial,
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
 // The packed gradient rows taken apart again for the three-call form (autograd hands d_gaussians2d / d_features on to the
 // caller's own graph): one sequential sweep in splat order.
 template <int C>
-__global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restrict__ grows, int64_t M,
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restrict__ rows,
+                                                          const float* __restrict__ grows, int64_t M,
                                                           float* __restrict__ dg2d, float* __restrict__ dfeat,
                                                           float* __restrict__ prune, float* __restrict__ split,
                                                           float* __restrict__ vis) {
@@ -238,10 +240,14 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restric
   if (m >= M) return;
   const float4* gr = reinterpret_cast<const float4*>(grows + GSR_ROW_FLOATS * m);
   const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2];
+  // moments of G dL/dG about the mean -> d(u, v, A, B, C), with the conic of the forward row (composite.hip, K7)
+  const float4* fr = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * m);
+  const float4 f0 = fr[0];
+  const float cA = f0.z, cB = f0.w, cC = fr[1].x;
   float* g = dg2d + 6 * m;
-  *reinterpret_cast<float2*>(g) = make_float2(g0.x, g0.y);
-  *reinterpret_cast<float2*>(g + 2) = make_float2(g0.z, g0.w);
-  *reinterpret_cast<float2*>(g + 4) = make_float2(g1.x, g1.y);
+  *reinterpret_cast<float2*>(g) = make_float2(cA * g0.x + cB * g0.y, cB * g0.x + cC * g0.y);
+  *reinterpret_cast<float2*>(g + 2) = make_float2(-0.5f * g0.z, -g0.w);
+  *reinterpret_cast<float2*>(g + 4) = make_float2(-0.5f * g1.x, g1.y);
   if (prune) prune[m] = g1.z;
   if (split) split[m] = g1.w;
   if (vis) vis[m] = g2.w;
@@ -344,17 +350,18 @@ int gsr_reduce_gradients(const float* partial, const float* vis_partial, const u
   return GSR_OK;
 }
 
-int gsr_unpack_grad_rows(const float* grad_rows, int64_t M, int32_t C, float* d_gaussians2d, float* d_features,
-                         float* prune_cost_out, float* split_score_out, float* visibility_out, void* stream_) {
+int gsr_unpack_grad_rows(const float* rows, const float* grad_rows, int64_t M, int32_t C, float* d_gaussians2d,
+                         float* d_features, float* prune_cost_out, float* split_score_out, float* visibility_out,
+                         void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
   if (C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
-  if (!grad_rows || !d_gaussians2d || !d_features) return GSR_ERR_INVALID_ARGUMENT;
+  if (!rows || !grad_rows || !d_gaussians2d || !d_features) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
-  if (C == 1) unpack_rows_kernel<1><<<g, 256, 0, stream>>>(grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
-  else if (C == 2) unpack_rows_kernel<2><<<g, 256, 0, stream>>>(grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
-  else unpack_rows_kernel<3><<<g, 256, 0, stream>>>(grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
+  if (C == 1) unpack_rows_kernel<1><<<g, 256, 0, stream>>>(rows, grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
+  else if (C == 2) unpack_rows_kernel<2><<<g, 256, 0, stream>>>(rows, grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
+  else unpack_rows_kernel<3><<<g, 256, 0, stream>>>(rows, grad_rows, M, d_gaussians2d, d_features, prune_cost_out, split_score_out, visibility_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -45,14 +45,40 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // tile half (left/right 8x8 quadrant, same row => same dy) as ONE 2-wide packed computation, branch-free, with
 // non-contributing pixels masked to alpha = 0.  A half no lane needs is skipped by a wave-uniform branch.
 //
-// eval_q2 / eval_G2 are shared by forward and backward and pin every rounding (explicit fma, contraction off), so
-// both passes take bit-identical contribute / skip decisions.
-__device__ __forceinline__ v2f eval_q2(v2f dx, float dy, float A, float B2, float C) {
+// eval_q2 / eval_qt / eval_G2 are shared by forward and backward and pin every rounding (explicit fma, contraction
+// off), so both passes take bit-identical contribute / skip decisions.
+// GSR_QT_FORM 1 forms q as d . t with t = conic d (the backward pass needs t anyway: two packed operations instead of
+// six there).  Measured (same box, c2 / c3): K7 374 / 724 us against 380 / 735, but K6 228 / 715 against 203 / 721 -- the
+// forward kernel goes from 79 to 83 SGPRs and loses more on the frame the headline is quoted on than the backward pass
+// gains; capping its SGPRs at 80 leaves it at 212 / 743.  Default: the direct quadratic form in both.
+#ifndef GSR_QT_FORM
+#define GSR_QT_FORM 0
+#endif
+__device__ __forceinline__ v2f eval_q2(v2f dx, float dy, float A, float B, float C) {
 #pragma clang fp contract(off)
-  // q = A dx^2 + 2B dx dy + C dy^2,   B2 = 2B
-  const float t = B2 * dy;
+#if GSR_QT_FORM
+  const float bdy = B * dy, cdy = C * dy;
+  const v2f tx = __builtin_elementwise_fma(dx, GSR_V2(A), GSR_V2(bdy));
+  const v2f ty = __builtin_elementwise_fma(dx, GSR_V2(B), GSR_V2(cdy));
+  return __builtin_elementwise_fma(GSR_V2(dy), ty, dx * tx);
+#else
+  // q = A dx^2 + 2B dx dy + C dy^2
+  const float t = (B + B) * dy;
   const float u = (C * dy) * dy;
   return __builtin_elementwise_fma(dx * A, dx, __builtin_elementwise_fma(GSR_V2(t), dx, GSR_V2(u)));
+#endif
+}
+// ... and t = conic d = (A dx + B dy, B dx + C dy) next to it (backward: gradient of the mean, split score)
+__device__ __forceinline__ void eval_qt(v2f dx, float dy, float A, float B, float C, v2f& q, v2f& tx, v2f& ty) {
+#pragma clang fp contract(off)
+  const float bdy = B * dy, cdy = C * dy;
+  tx = __builtin_elementwise_fma(dx, GSR_V2(A), GSR_V2(bdy));
+  ty = __builtin_elementwise_fma(dx, GSR_V2(B), GSR_V2(cdy));
+#if GSR_QT_FORM
+  q = __builtin_elementwise_fma(GSR_V2(dy), ty, dx * tx);
+#else
+  q = eval_q2(dx, dy, A, B, C);
+#endif
 }
 __device__ __forceinline__ v2f eval_G2(v2f q) {     // exp(-q/2) = 2^(q * -0.5*log2(e))
 #pragma clang fp contract(off)
@@ -145,14 +171,13 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
         if (i + m + 1 < end) nxt = load_splat<C>(rec, sorted_rank, i + m + 1);   // prefetch (scalar loads)
         const float dxa = fx0 - s.u, dya = fy0 - s.v;
         const v2f dx2 = {dxa, dxa + 8.f};
-        const float B2 = s.B + s.B;
         const int idx = (int)(i - tile_start) + m + 1;
         v2f wsum2 = GSR_V2(0.f);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           if (!(s.halves & (1u << h))) continue;                        // scalar test: support misses this half
           const float dy = h ? dya + 8.f : dya;
-          const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+          const v2f q = eval_q2(dx2, dy, s.A, s.B, s.C);
           const bool in0 = px.T2[h].x >= rp.T_eps && q.x <= rp.q_max;
           const bool in1 = px.T2[h].y >= rp.T_eps && q.y <= rp.q_max;
           if (__ballot(in0 || in1) != 0ull) {
@@ -228,12 +253,11 @@ __device__ __forceinline__ void seg_alpha_pass(uint32_t sidx, const float* __res
     if (i + 1 < end) nxt = load_splat<1>(rec, sorted_rank, i + 1);
     const float dxa = fx0 - s.u, dya = fy0 - s.v;
     const v2f dx2 = {dxa, dxa + 8.f};
-    const float B2 = s.B + s.B;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (!(s.halves & (1u << h))) continue;
       const float dy = h ? dya + 8.f : dya;
-      const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+      const v2f q = eval_q2(dx2, dy, s.A, s.B, s.C);
       const bool in0 = q.x <= rp.q_max, in1 = q.y <= rp.q_max;
       if (__ballot(in0 || in1) != 0ull) {
         v2f alpha = clamp_alpha2(eval_G2(q) * s.op, rp.clamp_max_alpha);
@@ -545,14 +569,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
       }
       const float dxa = fx0 - s.u, dya = fy0 - s.v;
       const v2f dx2 = {dxa, dxa + 8.f};
-      const float B2 = s.B + s.B;
-      v2f du2 = GSR_V2(0.f), dv2 = du2, dA2 = du2, dB2 = du2, dC2 = du2, dop2 = du2, prune2 = du2, split2 = du2;
-      v2f df2[3] = {du2, du2, du2};
+      // Per pair and pixel the geometry gradient enters through ONE scalar, GdG = G dL/dG; what is accumulated are its
+      // moments about the splat's mean, sum GdG {dx, dy, dx^2, dx dy, dy^2} -- fewer packed operations per half than
+      // accumulating du, dv, dA, dB, dC themselves -- and the per-splat sweep that consumes the reduced rows converts
+      // them once per splat:  du = A mx + B my, dv = B mx + C my, dA = -mxx / 2, dB = -mxy, dC = -myy / 2.
+      v2f mx2 = GSR_V2(0.f), my2 = mx2, mxx2 = mx2, mxy2 = mx2, myy2 = mx2, dop2 = mx2, prune2 = mx2, split2 = mx2;
+      v2f df2[3] = {mx2, mx2, mx2};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (!(s.halves & (1u << h))) continue;                            // scalar test: support misses this half
         const float dy = h ? dya + 8.f : dya;
-        const v2f q = eval_q2(dx2, dy, s.A, B2, s.C);
+        v2f q, tx_, ty_;
+        eval_qt(dx2, dy, s.A, s.B, s.C, q, tx_, ty_);
         const bool in0 = pos < lastc[2 * h] && q.x <= rp.q_max;
         const bool in1 = pos < lastc[2 * h + 1] && q.y <= rp.q_max;
         if (__ballot(in0 || in1) != 0ull) {
@@ -575,7 +603,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
           if (C > 2) df2[2] = __builtin_elementwise_fma(w, g2[h][2], df2[2]);
           const v2f dLda = Tb * gc - ga2[h] * inv;           // dC/dalpha = T c - (colour behind)/(1-alpha)
           ga2[h] = __builtin_elementwise_fma(gc, w, ga2[h]);
-          prune2 = __builtin_elementwise_fma(__builtin_elementwise_abs(dLda), alpha, prune2);
+          // |x| rides as a source modifier on the plain fma (the packed form would need a separate v_and per pixel)
+          prune2 = (v2f){__builtin_fmaf(__builtin_fabsf(dLda.x), alpha.x, prune2.x),
+                         __builtin_fmaf(__builtin_fabsf(dLda.y), alpha.y, prune2.y)};
           // gradient through G = exp(-q/2) only where the pixel contributed and the alpha clamp is inactive
           const bool m0 = hit0 && a_raw.x <= rp.clamp_max_alpha;
           const bool m1 = hit1 && a_raw.y <= rp.clamp_max_alpha;
@@ -583,21 +613,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
           GdL = (v2f){m0 ? GdL.x : 0.f, m1 ? GdL.y : 0.f};
           dop2 += GdL;
           const v2f GdG = GdL * s.op;                        // G * dL/dG
-          const v2f dq = GdG * -0.5f;
-          const v2f dqdx = dq * dx2;
-          dA2 = __builtin_elementwise_fma(dqdx, dx2, dA2);
-          dB2 = __builtin_elementwise_fma(dqdx, GSR_V2(2.f * dy), dB2);
-          dC2 = __builtin_elementwise_fma(dq, GSR_V2(dy * dy), dC2);
-          const v2f tx_ = __builtin_elementwise_fma(dx2, GSR_V2(s.A), GSR_V2(s.B * dy));
-          const v2f ty_ = __builtin_elementwise_fma(dx2, GSR_V2(s.B), GSR_V2(s.C * dy));
-          const v2f gmx = GdG * tx_, gmy = GdG * ty_;
-          du2 += gmx;
-          dv2 += gmy;
-          const v2f nn = __builtin_elementwise_fma(gmx, gmx, gmy * gmy);
-          split2 += (v2f){__builtin_amdgcn_sqrtf(nn.x), __builtin_amdgcn_sqrtf(nn.y)};
+          const v2f px_ = GdG * dx2, py_ = GdG * dy;
+          mx2 += px_;
+          my2 += py_;
+          mxx2 = __builtin_elementwise_fma(px_, dx2, mxx2);
+          mxy2 = __builtin_elementwise_fma(px_, GSR_V2(dy), mxy2);
+          myy2 = __builtin_elementwise_fma(py_, GSR_V2(dy), myy2);
+          // split score: sum_px |dL_px/d(u,v)| = |GdG| |conic d|
+          const v2f nn = __builtin_elementwise_fma(ty_, ty_, tx_ * tx_);
+          split2 = (v2f){__builtin_fmaf(__builtin_fabsf(GdG.x), __builtin_amdgcn_sqrtf(nn.x), split2.x),
+                         __builtin_fmaf(__builtin_fabsf(GdG.y), __builtin_amdgcn_sqrtf(nn.y), split2.y)};
         }
       }
-      float du = du2.x + du2.y, dv = dv2.x + dv2.y, dA = dA2.x + dA2.y, dB = dB2.x + dB2.y, dC = dC2.x + dC2.y;
+      float du = mx2.x + mx2.y, dv = my2.x + my2.y, dA = mxx2.x + mxx2.y, dB = mxy2.x + mxy2.y, dC = myy2.x + myy2.y;
       float dop = dop2.x + dop2.y, prune = prune2.x + prune2.y, split = split2.x + split2.y;
       float df[3] = {df2[0].x + df2[0].y, df2[1].x + df2[1].y, df2[2].x + df2[2].y};
       // Per-pair reduction of the 11 sums over the tile's 256 pixels THROUGH LDS (the wave owns the block's LDS, no

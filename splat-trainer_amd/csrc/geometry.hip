@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256) void project_bwd_rows_kernel(
     const float* __restrict__ pos, const float* __restrict__ ls, const float* __restrict__ rot,
     const float* __restrict__ logit, const int64_t* __restrict__ idx, int64_t M, const int32_t* __restrict__ inv,
     int64_t N, const float* __restrict__ Tcw, const float* __restrict__ proj, GsrRasterParams rp,
-    const float* __restrict__ grows, const float* __restrict__ dg2d_extra, const float* __restrict__ ddepth,
+    const float* __restrict__ rows, const float* __restrict__ grows, const float* __restrict__ dg2d_extra,
+    const float* __restrict__ ddepth,
     const float* __restrict__ jac, float* __restrict__ dpos, float* __restrict__ dls, float* __restrict__ drot,
     float* __restrict__ dlogit, float* __restrict__ dcol_out, float* __restrict__ prune_out,
     float* __restrict__ split_out, float* __restrict__ vis_out) {
@@ -410,7 +411,12 @@ __global__ __launch_bounds__(256) void project_bwd_rows_kernel(
   float s[3] = {ls[3 * i], ls[3 * i + 1], ls[3 * i + 2]};
   const float4 qv = *reinterpret_cast<const float4*>(rot + 4 * i);
   float q[4] = {qv.x, qv.y, qv.z, qv.w};
-  float g[6] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y};
+  // the rows carry the MOMENTS of G dL/dG about the mean (composite.hip, K7): mx my mxx mxy | myy dop ...; with the
+  // conic the composite kernels used (same bits, from the forward row) they become d(u, v, A, B, C)
+  const float4* fr = reinterpret_cast<const float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
+  const float4 f0 = fr[0];
+  const float cA = f0.z, cB = f0.w, cC = fr[1].x;
+  float g[6] = {cA * g0.x + cB * g0.y, cB * g0.x + cC * g0.y, -0.5f * g0.z, -g0.w, -0.5f * g1.x, g1.y};
   if (dg2d_extra) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) g[k] += dg2d_extra[6 * m + k];
@@ -651,7 +657,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 17; }
+int gsr_abi_version(void) { return 18; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -789,7 +795,7 @@ int gsr_pack_rows(const float* gaussians2d, const float* depth, const float* fea
 int gsr_project_backward_rows(const float* position, const float* log_scaling, const float* rotation_xyzw,
                               const float* alpha_logit, const int64_t* indexes, int64_t M, const int32_t* inverse,
                               int64_t N, const float* T_camera_world, const float* projection,
-                              const GsrRasterParamsC* params_host, const float* grad_rows,
+                              const GsrRasterParamsC* params_host, const float* rows, const float* grad_rows,
                               const float* dL_dgaussians2d_extra, const float* dL_ddepth, const float* jacobian,
                               float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,
                               int32_t mode, float* d_colors_out, float* prune_cost_out, float* split_score_out,
@@ -803,11 +809,11 @@ int gsr_project_backward_rows(const float* position, const float* log_scaling, c
   if (mode == 2 && (!geom || (!inverse && M != N))) return GSR_ERR_INVALID_ARGUMENT;   // identity map only when all rows are visible
   if (mode != 2 && M == 0) return GSR_OK;
   if (mode == 2 && N == 0) return GSR_OK;
-  if (M > 0 && !grad_rows) return GSR_ERR_INVALID_ARGUMENT;
+  if (M > 0 && (!grad_rows || (geom && !rows))) return GSR_ERR_INVALID_ARGUMENT;
   const GsrRasterParams rp = to_params(params_host);
 #define GSR_LAUNCH_PBR(MODE, COUNT)                                                                                      \
   project_bwd_rows_kernel<MODE><<<grid_for(COUNT, 256), 256, 0, stream>>>(                                               \
-      position, log_scaling, rotation_xyzw, alpha_logit, indexes, M, inverse, N, T_camera_world, projection, rp,         \
+      position, log_scaling, rotation_xyzw, alpha_logit, indexes, M, inverse, N, T_camera_world, projection, rp, rows,   \
       grad_rows, dL_dgaussians2d_extra, dL_ddepth, jacobian, d_position, d_log_scaling, d_rotation, d_alpha_logit,       \
       d_colors_out, prune_cost_out, split_score_out, visibility_out)
   if (mode == 2) GSR_LAUNCH_PBR(2, N);

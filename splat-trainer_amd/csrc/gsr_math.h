@@ -45,7 +45,12 @@ GSR_HD void gsr_to_camera(const GsrCam& c, float px, float py, float pz, float& 
 #endif
   x = fmaf(c.R[0], px, fmaf(c.R[1], py, fmaf(c.R[2], pz, c.t[0])));
   y = fmaf(c.R[3], px, fmaf(c.R[4], py, fmaf(c.R[5], pz, c.t[1])));
-  z = fmaf(c.R[6], px, fmaf(c.R[7], py, fmaf(c.R[8], pz, c.t[2])));
+  // The depth is formed in double and rounded once: it is the SORT KEY of the frame, and at millions of splats
+  // neighbouring depths are an fp32 ulp apart -- a depth that is off by one ulp orders nearly coplanar splats differently
+  // from the (fp64) specification.  Products of two floats are exact in double, so this is the correctly rounded value
+  // of R p + t (up to double rounding, probability ~1e-9 per splat) and the depth ORDER can be checked against a stable
+  // argsort of the oracle's depths (tests/test_gpu_render.py, config 3).  Three DFMAs per splat in HBM-bound kernels.
+  z = (float)fma((double)c.R[6], (double)px, fma((double)c.R[7], (double)py, fma((double)c.R[8], (double)pz, (double)c.t[2])));
 }
 
 // centre-in-frustum test (K1).  The expanded image bound keeps x/z, y/z bounded for K2.

@@ -575,7 +575,7 @@ class _RasterFn(torch.autograd.Function):
     if live:
       grows = _composite_backward_rows(st, d_image, dev)
       # prune_cost / split_score (/ visibility) are written straight into the tensors the Rendering already holds
-      _lib.check(lib.gsr_unpack_grad_rows(_ptr(grows), st.M, st.C, _ptr(d_g2d), _ptr(d_feat), _ptr(st.prune_cost),
+      _lib.check(lib.gsr_unpack_grad_rows(_ptr(st.rows), _ptr(grows), st.M, st.C, _ptr(d_g2d), _ptr(d_feat), _ptr(st.prune_cost),
                                           _ptr(st.split_score), _ptr(_vis_out(st, live)), _stream()),
                  "gsr_unpack_grad_rows")
     return d_g2d.to(ctx.in_dtypes[0]), d_feat.to(ctx.in_dtypes[1]), None, None, None
@@ -670,7 +670,8 @@ class _FrameFn(torch.autograd.Function):
       dcol = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_sh else None
       _lib.check(lib.gsr_project_backward_rows(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M,
                                                _ptr(inv) if mode == 2 else None, N, _ptr(T), _ptr(proj),
-                                               C.byref(st.params), _ptr(grows), _ptr(dg), _ptr(dd), _ptr(ctx.jac),
+                                               C.byref(st.params), _ptr(st.rows), _ptr(grows), _ptr(dg), _ptr(dd),
+                                               _ptr(ctx.jac),
                                                _ptr(d_pos), _ptr(d_ls), _ptr(d_rot), _ptr(d_al), mode, _ptr(dcol),
                                                _ptr(st.prune_cost) if live else None,
                                                _ptr(st.split_score) if live else None, _ptr(_vis_out(st, live)),

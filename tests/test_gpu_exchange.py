@@ -39,7 +39,7 @@ def _scene(culled: bool):
   return g, [c.to("cuda") for c in cams]
 
 
-def _run(g, cams, **step_options):
+def _run(g, cams, batches=2, **step_options):
   params = [t.clone().cuda().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
   scene = sta.Gaussians3D(position=params[0], rotation=params[2], log_scaling=params[1], alpha_logit=params[3], feature=params[4])
   target = torch.full((cams[0].image_size[1], cams[0].image_size[0], 3), 0.5, device="cuda")
@@ -52,7 +52,7 @@ def _run(g, cams, **step_options):
 
   dp = CameraShardedStep(params, 1, 0, **step_options)
   state = PointState.new_zeros(params[0].shape[0], "cuda")
-  for _ in range(2):                                     # two batches: everything per-batch must reset in between
+  for _ in range(batches):                               # two batches: everything per-batch must reset in between
     dp.run(cams, render_backward, point_state=state)
   return {k: v.clone() for k, v in dp.grads.items()}, state, dp.visible.clone()
 
@@ -70,6 +70,31 @@ def test_dense_exchange_on_one_rank_equals_the_sequential_loop(one_rank_group, c
     scale = want_g[k].abs().max().clamp_min(1e-20)
     assert (got_g[k] - want_g[k]).abs().max() / scale < 2e-5, k
   assert want_s.points_in_view.max() >= 2 and want_s.split_score.abs().max() > 0
+
+
+def test_config3_batch_goes_through_the_exchange(one_rank_group):
+  """BASELINE.json configs[2] at full size -- 3M Gaussians, 1080p, SH degree 3, the batch of 8 orbit cameras -- through
+  the default exchange on the one-rank RCCL group: 8 dense 72 MB camera blocks packed and all-gathered, the 156 MB
+  all-reduce, the SH gradient rebuilt from the factors of all 8 cameras and their controller scores replayed in camera
+  order, against the sequential loop over the same cameras.  Everything the densification masks are made of must be
+  bit-identical; gradients agree up to the association order of the sums."""
+  g, cams = synthetic.scene_b(3_000_000, 1920, 1080, sh_degree=3, seed=1, num_cameras=8)
+  cams = [c.to("cuda") for c in cams]
+  want_g, want_s, want_v = _run(g, cams, batches=1)
+  got_g, got_s, got_v = _run(g, cams, batches=1, exchange_when_single=True)
+  for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view"):
+    assert torch.equal(getattr(got_s, f), getattr(want_s, f)), f
+  assert torch.allclose(got_s.visibility, want_s.visibility, rtol=1e-5, atol=1e-6)
+  assert torch.allclose(got_v, want_v, rtol=1e-5, atol=1e-6)
+  for k in want_g:
+    scale = want_g[k].abs().max().clamp_min(1e-20)
+    assert (got_g[k] - want_g[k]).abs().max() / scale < 2e-5, k
+  assert int(want_s.points_in_view.max()) == 8 and want_s.split_score.abs().max() > 0
+  # the masks themselves, through the reference's controller rule (target_controller.py:150-160 via controller_math)
+  from splat_trainer_amd.controller_math import find_split_prune_indexes
+  a = find_split_prune_indexes(want_s, 0.25, 3_300_000, min_views=5, max_scale_px=200.0)
+  b = find_split_prune_indexes(got_s, 0.25, 3_300_000, min_views=5, max_scale_px=200.0)
+  assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and bool(a[0].any())
 
 
 def test_dp_pack_and_replay_match_their_cpu_forms():

@@ -234,42 +234,88 @@ def test_config2_full_size_matches_oracle_everywhere():
 
 
 def test_config3_full_size_sampled_tiles_match_oracle():
-  """BASELINE.json configs[2], one camera (3M Gaussians, 1080p, SH degree 3; ~800 pairs on every tile): the projection
-  outputs of all 3M points and the composited image / final T of a fixed sample of 384 tiles against the fp64 oracle
-  (the whole image would take the host minutes; c2 is compared in full above)."""
+  """BASELINE.json configs[2], one camera (3M Gaussians, 1080p, SH degree 3; ~800 pairs on every tile), against the fp64
+  oracle: the projection outputs of all 3M points; the depth ORDER (the HIP depths must be the oracle's fp64 depths
+  rounded to fp32, bit for bit, so that the stable sort sees the same keys: at 3M splats neighbouring depths are one
+  fp32 ulp apart); the composited image / final T of a fixed sample of 384 tiles; and -- for the loss restricted to those
+  tiles -- ALL parameter gradients of all 3M points and the two backward heuristics (a loss that only looks at the
+  sampled tiles has gradients the oracle can form from those tiles alone; the whole image would take the host minutes,
+  c2 is compared in full above)."""
   n, w, h = 3_000_000, 1920, 1080
   g, cams = synthetic.scene_b(n, w, h, sh_degree=3, seed=1, num_cameras=8)
   cam = cams[0]
   camd = cam.to("cuda")
-  gd = sta.Gaussians3D(*(t.cuda() for t in (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
-  with torch.no_grad():
-    r = sta.render_gaussians(gd, camd, CFG, use_sh=True)
-  dt = torch.float64
-  T, proj = cam.T_camera_world.to(dt), cam.projection.to(dt)
-  idx = oracle.frustum_cull(g.position.to(dt), T, proj, cam.image_size, cam.near_plane, cam.far_plane,
-                            CFG.margin_tiles * CFG.tile_size)
-  assert torch.equal(r.points.idx.cpu(), idx)
-  g2d, depth, sscale = oracle.project(g.position.to(dt), g.log_scaling.to(dt), g.rotation.to(dt), g.alpha_logit.to(dt),
-                                      idx, T, proj, CFG)
-  R = T[:3, :3]
-  feats = oracle.evaluate_sh_at(g.feature.to(dt), g.position.to(dt), idx, -(R.t() @ T[:3, 3]))
-  assert observe("c3 full size 3M 1080p SH3", "depth", r.points.depths, depth, TOL)[0] < TOL
-  assert observe("c3 full size 3M 1080p SH3", "screen_scale", r.points.screen_scale, sscale, TOL)[0] < TOL
   tiles_x, tiles_y = (w + 15) // 16, (h + 15) // 16
   gen = torch.Generator().manual_seed(0)
   tiles = torch.randperm(tiles_x * tiles_y, generator=gen)[:384]
-  # Depth ORDER from the fp32 depths the projection produced: at 3M splats neighbouring depths are one fp32 ulp apart, so
-  # the fp64 depths would order thousands of nearly coplanar splat pairs differently (ties break by index in fp32) --
-  # the transmittance would still agree, the colours of those pixels would not.  The values compared are the oracle's.
-  out = oracle.rasterize(g2d, r.points.depths.cpu().to(dt), feats, (w, h), CFG, tiles=tiles)
-  img, fT = r.image.cpu(), r.final_transmittance.cpu()
   mask = torch.zeros(h, w, dtype=torch.bool)
   for t in tiles.tolist():
     ty, tx = t // tiles_x, t % tiles_x
     mask[ty * 16:min(ty * 16 + 16, h), tx * 16:min(tx * 16 + 16, w)] = True
-  worst_i, frac_i = observe("c3 full size 3M 1080p SH3", "image (384 tiles)", img[mask], out.image[mask], TOL)
-  worst_t, frac_t = observe("c3 full size 3M 1080p SH3", "final_T (384 tiles)", fT[mask], out.final_T[mask], TOL)
+  norm = float(mask.sum()) * 3
+
+  # HIP: full frame, loss over the sampled tiles only
+  leaves = [t.clone().cuda().requires_grad_(True) for t in (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)]
+  r = sta.render_gaussians(sta.Gaussians3D(*leaves), camd, CFG, use_sh=True)
+  (((r.image.clamp(0, 1) - 0.5) ** 2) * mask.cuda()[..., None]).sum().div(norm).mul(100.0).backward()
+  hip = dict(d_position=leaves[0].grad, d_rotation=leaves[1].grad, d_log_scaling=leaves[2].grad,
+             d_alpha_logit=leaves[3].grad, d_feature=leaves[4].grad, prune_cost=r.points.prune_cost,
+             split_score=r.points.split_score)
+
+  # oracle: fp64, the same loss; the composite stage runs over the sampled tiles only, chunk by chunk
+  dt = torch.float64
+  ol = [t.clone().to(dt).requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+  T, proj = cam.T_camera_world.to(dt), cam.projection.to(dt)
+  idx = oracle.frustum_cull(ol[0], T, proj, cam.image_size, cam.near_plane, cam.far_plane, CFG.margin_tiles * CFG.tile_size)
+  assert torch.equal(r.points.idx.cpu(), idx)
+  g2d, depth, sscale = oracle.project(ol[0], ol[1], ol[2], ol[3], idx, T, proj, CFG)
+  R = T[:3, :3]
+  feats = oracle.evaluate_sh_at(ol[4], ol[0], idx, -(R.t() @ T[:3, 3]))
+  label = "c3 full size 3M 1080p SH3"
+  assert observe(label, "depth", r.points.depths, depth.detach(), TOL)[0] < TOL
+  assert observe(label, "screen_scale", r.points.screen_scale, sscale.detach(), TOL)[0] < TOL
+  # the sort keys: HIP's fp32 depths ARE the oracle's depths rounded to fp32 (gsr_math.h: the depth is formed in double
+  # and rounded once), so a stable fp32 argsort of the oracle's depths is the order the HIP frame was composited in
+  depth32 = depth.detach().float().reshape(-1)
+  differ = int((r.points.depths.detach().cpu().reshape(-1) != depth32).sum())
+  print(f"c3: HIP depth != fp32(oracle depth) at {differ} of {depth32.numel()} splats")
+  assert differ <= 3
+  g2d_d, feats_d = g2d.detach().requires_grad_(True), feats.detach().requires_grad_(True)
+  order_depth = depth32.to(dt)                     # order by the fp32 keys (ties by index), values stay the oracle's own
+  lists = oracle._tile_lists(g2d_d, order_depth, (w, h), CFG)
+  img_o = torch.zeros(h, w, 3, dtype=dt)
+  fT_o = torch.ones(h, w, dtype=dt)
+  M = idx.shape[0]
+  prune, split = torch.zeros(M, dtype=dt), torch.zeros(M, dtype=dt)
+  for c0 in range(0, tiles.numel(), 96):
+    chunk = tiles[c0:c0 + 96]
+    out = oracle.rasterize(g2d_d, order_depth, feats_d, (w, h), CFG, tiles=chunk, lists=lists)
+    img = out.image
+    img.retain_grad()
+    # pixels outside the chunk are zeros in `img`; the mask keeps them out of the loss
+    cm = torch.zeros(h, w, dtype=torch.bool)
+    for t in chunk.tolist():
+      ty, tx = t // tiles_x, t % tiles_x
+      cm[ty * 16:min(ty * 16 + 16, h), tx * 16:min(tx * 16 + 16, w)] = True
+    (((img.clamp(0, 1) - 0.5) ** 2) * cm[..., None]).sum().div(norm).mul(100.0).backward()
+    with torch.no_grad():
+      heur = oracle.rasterize(g2d_d.detach(), order_depth, feats_d.detach(), (w, h), CFG, tiles=chunk, lists=lists,
+                              dL_dimage=img.grad)
+      img_o += out.image.detach() * cm[..., None]
+      fT_o = torch.where(cm, out.final_T, fT_o)
+      prune += heur.prune_cost
+      split += heur.split_score
+  torch.autograd.backward([g2d, feats], [g2d_d.grad, feats_d.grad])
+  img, fT = r.image.detach().cpu(), r.final_transmittance.cpu()
+  worst_i, frac_i = observe(label, "image (384 tiles)", img[mask], img_o[mask], TOL)
+  worst_t, frac_t = observe(label, "final_T (384 tiles)", fT[mask], fT_o[mask], TOL)
   assert frac_i <= 1e-4 and frac_t <= 1e-4 and worst_i < 1e-2 and worst_t < 1e-2, (worst_i, frac_i, worst_t, frac_t)
+  orc = dict(d_position=ol[0].grad, d_log_scaling=ol[1].grad, d_rotation=ol[2].grad, d_alpha_logit=ol[3].grad,
+             d_feature=ol[4].grad, prune_cost=prune, split_score=split)
+  for k in ("d_position", "d_log_scaling", "d_rotation", "d_alpha_logit", "d_feature", "prune_cost", "split_score"):
+    worst, frac = observe(label + " (loss on 384 tiles)", k, hip[k], orc[k], TOL)
+    assert frac <= 2e-4 and worst < 1e-2, (k, worst, frac)
+    assert orc[k].abs().max() > 0
 
 
 @pytest.mark.parametrize("n,w,h,deg", [(3_000_000, 1920, 1080, 3), (10_000_000, 3840, 2160, 3)])

@@ -74,7 +74,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 18) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 19) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -206,7 +206,9 @@ int gsr_pack_rows(const float* gaussians2d, const float* depth, const float* fea
  * tile counts when the support reaches the pixel centres of its upper or lower half) and tile_hits_out [M,4] uint32:
  * which tiles of the splat's extent were counted and which halves of each, for gsr_tile_emit (opaque to the caller). */
 int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t W, int32_t H,
-                   const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out, void* stream);
+                   const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out,
+                   const uint32_t* M_dev /* NULL, or the device word with the visible count when M is a capacity: ranks at
+                                            or beyond it get count 0 */, void* stream);
 /* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id and
  * inst2splat[...] = order[k] | (half mask << 30): instances are emitted rank-major (already depth-sorted), the value they
  * carry is the splat id the composite kernels fetch the row by.
@@ -215,7 +217,7 @@ int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t 
  * the total with the capacity afterwards and emits again if it was too small). */
 int gsr_tile_emit(const float* rows, const uint32_t* order, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M,
                   int32_t W, int32_t H, const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2splat_out,
-                  int64_t capacity, void* stream);
+                  int64_t capacity, const uint32_t* M_dev /* as gsr_tile_count */, void* stream);
 /* From the tile-sorted keys: per-tile [start, end).  tile_range must be zero-filled by the caller:
  * [num_tiles, 2] uint32. */
 int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, uint32_t* tile_range,
@@ -269,7 +271,8 @@ int gsr_composite_backward(const float* rows /* [M,16] */, const uint32_t* sorte
 /* visibility_out [M] indexed by splat (not rank).  capacity = slots vis_partial holds (the pair count, or the bound
  * the buffers were sized with: slots at or beyond it are not read). */
 int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
-                          const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity, void* stream);
+                          const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity,
+                          const uint32_t* M_dev /* as gsr_tile_count */, void* stream);
 /* grad_rows_out [M,16] indexed by splat, each row written whole (the one crossing of the depth-order permutation on the
  * backward side):  mx my mxx mxy | myy dop prune_cost split_score | df0 df1 df2 visibility | 0 0 0 0  (m*: the summed
  * moments of GSR_PARTIAL_FLOATS; gsr_project_backward_rows / gsr_unpack_grad_rows turn them into d(u, v, A, B, C) with
@@ -281,6 +284,62 @@ int gsr_reduce_gradients(const float* partial, const float* vis_partial, const u
 int gsr_unpack_grad_rows(const float* rows /* the forward rows [M,16] */, const float* grad_rows, int64_t M, int32_t C,
                          float* d_gaussians2d, float* d_features, float* prune_cost_out, float* split_score_out,
                          float* visibility_out, void* stream);
+
+/* ---- frame driver: the forward half of render_gaussians(use_sh = True) behind one call ---------------------
+ * (scene.render -> project_to_image + evaluate_sh_at + render_projected, splat_trainer/scene/mlp_scene.py:410-427 /
+ * scripts/test_split.py:30.)  The same launches as the single entry points above, chained with the two data-dependent
+ * sizes of a frame left on the device: kernels run over the N scene rows and stop at the visible count M (counts[0]),
+ * pair buffers hold `pair_capacity` pairs and every kernel reads the pair count O (counts[1]) on the device.  The host
+ * reads counts[0..2] = [M, O, overflow flag] back afterwards; when O > pair_capacity the frame is run again with a
+ * larger capacity (nothing in the results depends on the capacity or on N as a bound).  C = 3 feature channels. */
+typedef struct GsrFrameC {
+  const float* position;        /* [N,3] */
+  const float* log_scaling;     /* [N,3] */
+  const float* rotation_xyzw;   /* [N,4] */
+  const float* alpha_logit;     /* [N]   */
+  const float* sh_features;     /* [N,3,K] */
+  int64_t N;
+  int32_t K;                    /* 1, 4, 9 or 16 */
+  int32_t W, H;
+  const float* T_camera_world;  /* 16 floats */
+  const float* projection;      /* fx fy cx cy */
+  const float* camera_pos;      /* 3 floats */
+  float near_plane, far_plane;
+  GsrRasterParamsC params;
+  int32_t want_jacobian;        /* save d colour / d position [M,9] for the backward pass */
+  int32_t want_median;
+  int32_t compute_visibility;
+  int32_t needs_grad;           /* a backward pass will follow: per-pair visibility + checkpoints are kept */
+  int32_t seg_pairs, seg_min_pairs;   /* RasterConfig.segment_pairs / segment_min_pairs */
+  int64_t pair_capacity;
+} GsrFrameC;
+/* Byte offsets of the frame's buffers inside the two caller-owned arenas (-1: not present in this frame).  `out`:
+ * everything the Rendering or the backward pass still needs after the forward pass; the first zero_bytes bytes are
+ * zero-filled by the driver.  `work`: scratch that may be freed as soon as the forward pass has run. */
+typedef struct GsrFramePlanC {
+  int64_t out_bytes, work_bytes;
+  int64_t zero_begin, zero_bytes;
+  /* out arena */
+  int64_t prune_cost, split_score, counts, tile_range, vis_partial, indexes, rows, screen_scale, jacobian, visibility,
+      image, final_T, last, median, count, offsets, vals_a, vals_b, tvals_a, tvals_b, trank_a, trank_b, pair_vis,
+      seg_tables, seg_pix, seg_last;
+  int64_t seg_capacity, seg_heavy_capacity;
+  /* work arena */
+  int64_t cull_ws, sort_ws, scan_ws, tsort_ws, keys_a, keys_b, tile_hits, tkeys_a, tkeys_b;
+  int64_t cull_ws_bytes, sort_ws_bytes, scan_ws_bytes, tsort_ws_bytes;
+} GsrFramePlanC;
+/* Where the ping-pong sorts left their results (byte offsets into `out`) and the segment tables of the frame. */
+typedef struct GsrFrameResultC {
+  int64_t order;          /* [N] u32: splat id by depth rank (first M valid) */
+  int64_t sorted_inst;    /* [pair_capacity] u32, or -1 when pair_capacity == 0 */
+  int64_t sorted_splat;   /* [pair_capacity] u32 */
+  GsrSegmentsC segments;  /* device pointers into `out`; valid when has_segments */
+  int32_t has_segments;
+} GsrFrameResultC;
+int gsr_frame_plan(const GsrFrameC* frame_host, GsrFramePlanC* plan_out_host);
+/* event_k6_begin / event_k6_end: hipEvent_t recorded around the composite launch (bench.py's roofline leg), or NULL. */
+int gsr_frame_forward(const GsrFrameC* frame_host, const GsrFramePlanC* plan_host, void* out_arena, void* work_arena,
+                      GsrFrameResultC* result_out_host, void* event_k6_begin, void* event_k6_end, void* stream);
 
 /* ---- loss stage next to the path: fused SSIM, replaces the CUDA-only fused_ssim package
  *      the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462; trainer/evaluation.py:7,42) ------------ */

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class GsrRasterParamsC(C.Structure):
@@ -27,6 +27,33 @@ class GsrSegmentsC(C.Structure):
   _fields_ = [("tile_seg", C.c_void_p), ("seg_desc", C.c_void_p), ("seg_total", C.c_void_p), ("capacity", C.c_int64),
               ("heavy_capacity", C.c_int64), ("seg_P", C.c_void_p), ("seg_TC", C.c_void_p), ("seg_last", C.c_void_p),
               ("seg_median", C.c_void_p)]
+
+
+class GsrFrameC(C.Structure):
+  _fields_ = [("position", C.c_void_p), ("log_scaling", C.c_void_p), ("rotation_xyzw", C.c_void_p),
+              ("alpha_logit", C.c_void_p), ("sh_features", C.c_void_p), ("N", C.c_int64), ("K", C.c_int32),
+              ("W", C.c_int32), ("H", C.c_int32), ("T_camera_world", C.c_void_p), ("projection", C.c_void_p),
+              ("camera_pos", C.c_void_p), ("near_plane", C.c_float), ("far_plane", C.c_float),
+              ("params", GsrRasterParamsC), ("want_jacobian", C.c_int32), ("want_median", C.c_int32),
+              ("compute_visibility", C.c_int32), ("needs_grad", C.c_int32), ("seg_pairs", C.c_int32),
+              ("seg_min_pairs", C.c_int32), ("pair_capacity", C.c_int64)]
+
+
+FRAME_PLAN_FIELDS = ("out_bytes", "work_bytes", "zero_begin", "zero_bytes", "prune_cost", "split_score", "counts",
+                     "tile_range", "vis_partial", "indexes", "rows", "screen_scale", "jacobian", "visibility", "image",
+                     "final_T", "last", "median", "count", "offsets", "vals_a", "vals_b", "tvals_a", "tvals_b", "trank_a",
+                     "trank_b", "pair_vis", "seg_tables", "seg_pix", "seg_last", "seg_capacity", "seg_heavy_capacity",
+                     "cull_ws", "sort_ws", "scan_ws", "tsort_ws", "keys_a", "keys_b", "tile_hits", "tkeys_a", "tkeys_b",
+                     "cull_ws_bytes", "sort_ws_bytes", "scan_ws_bytes", "tsort_ws_bytes")
+
+
+class GsrFramePlanC(C.Structure):
+  _fields_ = [(name, C.c_int64) for name in FRAME_PLAN_FIELDS]
+
+
+class GsrFrameResultC(C.Structure):
+  _fields_ = [("order", C.c_int64), ("sorted_inst", C.c_int64), ("sorted_splat", C.c_int64), ("segments", GsrSegmentsC),
+              ("has_segments", C.c_int32)]
 
 
 class GsrColumnC(C.Structure):
@@ -75,8 +102,8 @@ PROTOTYPES = {
     "gsr_project_backward_rows": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _p,
                                             _p, _p, _i32, _p, _p, _p, _p, _p]),
     "gsr_pack_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p]),
-    "gsr_tile_count": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p]),
-    "gsr_tile_emit": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p]),
+    "gsr_tile_count": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p, _p]),
+    "gsr_tile_emit": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p, _p]),
     "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "gsr_segment_thresholds": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _p, _p]),
     "gsr_segment_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
@@ -101,7 +128,10 @@ PROTOTYPES = {
     "gsr_dp_pack": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "gsr_dp_replay": (C.c_int, [_p, _i64, _p, _i32, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p]),
+    "gsr_frame_plan": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC)]),
+    "gsr_frame_forward": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC), _p, _p, C.POINTER(GsrFrameResultC), _p,
+                                    _p, _p]),
+    "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "gsr_unpack_grad_rows": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
 }

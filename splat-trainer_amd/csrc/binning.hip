@@ -62,9 +62,14 @@ __device__ __forceinline__ uint32_t hits_of_large_extent(float u, float v, float
 __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict__ rows,
                                                          const uint32_t* __restrict__ order, int64_t M, int tiles_x,
                                                          int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ count,
-                                                         TileHits* __restrict__ hits) {
+                                                         TileHits* __restrict__ hits,
+                                                         const uint32_t* __restrict__ M_dev) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
+  if (M_dev && k >= (int64_t)*M_dev) {        // M is a capacity: the visible count is still on the device
+    count[k] = 0u;                            // the scan over the capacity then needs no count of its own
+    return;
+  }
   const int64_t s = order[k];
   const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * s);
   const float4 r0 = r[0];
@@ -105,9 +110,10 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ offsets,
                                                         const TileHits* __restrict__ hits, int64_t M, int tiles_x,
                                                         int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ inst2splat, uint32_t capacity) {
+                                                        uint32_t* __restrict__ inst2splat, uint32_t capacity,
+                                                        const uint32_t* __restrict__ M_dev) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= M) return;
+  if (k >= M || (M_dev && k >= (int64_t)*M_dev)) return;
   const uint4 hw = *reinterpret_cast<const uint4*>(hits + k);
   uint32_t o = offsets[k];
   const uint32_t sid = order[k];
@@ -150,9 +156,10 @@ __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ count,
                                                          const uint32_t* __restrict__ order, int64_t M,
-                                                         float* __restrict__ vis, uint32_t limit) {
+                                                         float* __restrict__ vis, uint32_t limit,
+                                                         const uint32_t* __restrict__ M_dev) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= M) return;
+  if (k >= M || (M_dev && k >= (int64_t)*M_dev)) return;
   const uint32_t b = offsets[k], n = count[k];
   float acc = 0.f;
   // limit = slots vis_partial holds: a speculative launch (buffers sized from a guess that turned out too small) must
@@ -285,7 +292,8 @@ int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_ke
 }
 
 int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t W, int32_t H,
-                   const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out, void* stream_) {
+                   const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out,
+                   const uint32_t* M_dev, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || M >= (1ll << 30) || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
@@ -294,14 +302,14 @@ int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t 
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
   if (tx > 0xFFFF || ty > 0xFFFF) return GSR_ERR_UNSUPPORTED;      // the hit records hold 16-bit tile coordinates
   tile_count_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rows, order, M, tx, ty, to_params(params_host), count_out,
-                                                         reinterpret_cast<TileHits*>(tile_hits_out));
+                                                         reinterpret_cast<TileHits*>(tile_hits_out), M_dev);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
 
 int gsr_tile_emit(const float* rows, const uint32_t* order, const uint32_t* offsets, const uint32_t* tile_hits, int64_t M,
                   int32_t W, int32_t H, const GsrRasterParamsC* params_host, uint32_t* keys_out, uint32_t* inst2splat_out,
-                  int64_t capacity, void* stream_) {
+                  int64_t capacity, const uint32_t* M_dev, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || M >= (1ll << 30) || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (capacity < 0 || capacity > 0x7FFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
@@ -311,7 +319,7 @@ int gsr_tile_emit(const float* rows, const uint32_t* order, const uint32_t* offs
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
   tile_emit_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rows, order, offsets, reinterpret_cast<const TileHits*>(tile_hits),
                                                         M, tx, ty, to_params(params_host), keys_out, inst2splat_out,
-                                                        (uint32_t)capacity);
+                                                        (uint32_t)capacity, M_dev);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
@@ -328,13 +336,14 @@ int gsr_tile_ranges(const uint32_t* sorted_keys, int64_t O, int32_t num_tiles, u
 }
 
 int gsr_reduce_visibility(const float* vis_partial, const uint32_t* offsets, const uint32_t* count,
-                          const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity, void* stream_) {
+                          const uint32_t* order, int64_t M, float* visibility_out, int64_t capacity,
+                          const uint32_t* M_dev, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || capacity < 0 || capacity > 0x7FFFFFFFll) return GSR_ERR_INVALID_ARGUMENT;
   if (M == 0) return GSR_OK;
   if (!offsets || !count || !visibility_out) return GSR_ERR_INVALID_ARGUMENT;
   reduce_vis_kernel<<<grid_for(M, 256), 256, 0, stream>>>(vis_partial, offsets, count, order, M, visibility_out,
-                                                         (uint32_t)capacity);
+                                                         (uint32_t)capacity, M_dev);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -59,6 +59,12 @@ class KernelTimer:
   def begin(self, name: str):
     self._open[name] = self._event()
 
+  def pair(self, name: str):
+    """Two events for a native caller to record around a launch itself (frame driver): returns their raw handles."""
+    a, b = self._event(), self._event()
+    self.events.setdefault(name, []).append((a, b))
+    return C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)
+
   def end(self, name: str):
     self.events.setdefault(name, []).append((self._open.pop(name), self._event()))
 
@@ -296,7 +302,7 @@ class _RasterState:
     if not self.vis_ready:
       _lib.check(_lib.load().gsr_reduce_visibility(_ptr(self.vis_partial), _ptr(self.offsets), _ptr(self.count),
                                                    _ptr(self.order), self.M, _ptr(self.visibility), self.vis_capacity,
-                                                   _stream()), "gsr_reduce_visibility")
+                                                   None, _stream()), "gsr_reduce_visibility")
       self.vis_ready = True
     return self.visibility
 
@@ -434,7 +440,7 @@ def _bin_and_composite(rows: torch.Tensor, st: _RasterState, need_vis_partial: b
   total = (zeros_guess[fixed_zeros - 2:fixed_zeros].view(torch.int32) if zeros_guess is not None else
            torch.zeros(2, dtype=torch.int32, device=dev))         # [number of overlaps, overflow flag]
   _lib.check(lib.gsr_tile_count(_ptr(rows), _ptr(st.order), M, W, H, C.byref(st.params), _ptr(st.count), _ptr(tile_hits),
-                                stream), "gsr_tile_count")
+                                None, stream), "gsr_tile_count")
   scan_bytes = lib.gsr_scan_workspace_bytes(M)
   scan_ws = torch.empty(scan_bytes, dtype=torch.uint8, device=dev)
   _lib.check(lib.gsr_exclusive_scan_u32_checked(_ptr(st.count), _ptr(st.offsets), M, _ptr(total), _ptr(total[1:]),
@@ -447,7 +453,7 @@ def _bin_and_composite(rows: torch.Tensor, st: _RasterState, need_vis_partial: b
     kernel that needs the count reads it there, so the whole chain is enqueued before the count has reached the host."""
     tkeys_a, trank_a = _u32(capacity, dev), _u32(capacity, dev)
     _lib.check(lib.gsr_tile_emit(_ptr(rows), _ptr(st.order), _ptr(st.offsets), _ptr(tile_hits), M, W, H, C.byref(st.params),
-                                 _ptr(tkeys_a), _ptr(trank_a), capacity, stream), "gsr_tile_emit")
+                                 _ptr(tkeys_a), _ptr(trank_a), capacity, None, stream), "gsr_tile_emit")
     tkeys_b, tvals_a, tvals_b, trank_b = _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev)
     if zeros is None:
       zeros = zero_block(capacity)
@@ -581,11 +587,32 @@ class _RasterFn(torch.autograd.Function):
     return d_g2d.to(ctx.in_dtypes[0]), d_feat.to(ctx.in_dtypes[1]), None, None, None
 
 
+def _arena_view(arena: torch.Tensor, offset: int, shape, dtype) -> torch.Tensor:
+  n = 1
+  for d in shape:
+    n *= int(d)
+  return arena[offset:offset + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+
+
+def _pair_capacity(dev_index, N: int):
+  """Capacity of the frame's pair buffers: 1.25 x the largest recent pair count of this thread on this device (grows at
+  once, decays 1.5 % per frame), in steps of 1/16 of its power of two so that the arenas keep their sizes -- and the
+  caching allocator its blocks -- from frame to frame; a first frame starts from 4 pairs per scene row."""
+  guesses = _TLS.__dict__.setdefault("overlap_guess", {})
+  raw = guesses.get(dev_index, 0) if SPECULATE else 0
+  if raw <= 0:
+    raw = max(4 * N, 1 << 16)
+  step = 1 << max(raw.bit_length() - 5, 0)
+  return guesses, raw, min((raw + step - 1) // step * step, 0x7fffffff)
+
+
 class _FrameFn(torch.autograd.Function):
-  """The one-call form with SH colours as ONE autograd node: K1 cull -> fused K2 + K3 (one packed 64-byte row per
-  visible splat) -> K4..K6; backward = K7 -> packed gradient rows -> one sweep in splat order for the geometry
-  gradients and the per-point outputs -> SH coefficient gradient.  Outputs: image, gaussians2d (M,6) and depth (M,1)
-  (views of the rows; differentiable, so regularizers on points.opacity / points.depths reach the parameters), indexes."""
+  """The one-call form with SH colours as ONE autograd node.  Forward: the native frame driver (csrc/frame.hip) enqueues
+  K1 cull -> fused K2 + K3 (one packed 64-byte row per visible splat) -> K4 -> K5 -> K6 behind a single call, with the
+  visible count and the pair count left on the device; the host reads both back once, afterwards.  Backward: K7 -> packed
+  gradient rows -> one sweep in splat order for the geometry gradients and the per-point outputs -> SH coefficient
+  gradient.  Outputs: image, gaussians2d (M,6) and depth (M,1) (views of the rows; differentiable, so regularizers on
+  points.opacity / points.depths reach the parameters), indexes."""
 
   @staticmethod
   def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T, proj, cam_pos, cull_args, st: _RasterState,
@@ -595,34 +622,73 @@ class _FrameFn(torch.autograd.Function):
     sh, cam = _f32c(feature), _f32c(cam_pos)
     N, K, dev = pos.shape[0], sh.shape[2], pos.device
     W, H, near, far, margin = cull_args
-    stream = _stream()
-    indexes_full = torch.empty(N, dtype=torch.int64, device=dev)
-    count = torch.empty(1, dtype=torch.int32, device=dev)
-    ws_bytes = lib.gsr_cull_workspace_bytes(N)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    rows_full = torch.empty(N, ROW_FLOATS, dtype=torch.float32, device=dev)
-    scale_full = torch.empty(N, 2, dtype=torch.float32, device=dev)
-    keys_full = _u32(N, dev)
-    # d colour / d position is cheap to form while the coefficient row is in registers; saving it (36 B per splat)
-    # spares the backward pass a second sweep over the 12K-byte rows
-    jac_full = torch.empty(N, 9, dtype=torch.float32, device=dev) if (want_pos_grad and K > 1 and N > 0) else None
-    key_range = st.key_range
-    _lib.check(lib.gsr_frustum_cull(_ptr(pos), N, _ptr(T), _ptr(proj), W, H, near, far, margin, _ptr(indexes_full),
-                                    _ptr(count), _ptr(ws), ws_bytes, stream), "gsr_frustum_cull")
-    # enqueued with the visible count still on the device: the GPU works through the rows while the host reads it back
-    _lib.check(lib.gsr_project_sh_forward(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(sh), K, _ptr(indexes_full), N,
-                                          _ptr(T), _ptr(proj), _ptr(cam), C.byref(st.params), _ptr(rows_full),
-                                          _ptr(scale_full), _ptr(jac_full), _ptr(count), _ptr(keys_full), key_range[0],
-                                          key_range[1], stream), "gsr_project_sh_forward")
-    M = int(_start_readback(count)()[0])       # host sync #1: the size of ``indexes`` is data dependent
-    indexes, rows = indexes_full[:M], rows_full[:M]
-    st.M, st.screen_scale = M, scale_full[:M]
-    order = _launch_depth_order(None, M, key_range, keys=keys_full[:M]) if M > 0 else None
-    image = _bin_and_composite(rows, st, need_vis_partial=st.compute_visibility or st.needs_grad, order=order)
+    num_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    if N == 0:
+      indexes = torch.empty(0, dtype=torch.int64, device=dev)
+      rows = torch.empty(0, ROW_FLOATS, dtype=torch.float32, device=dev)
+      st.M = 0
+      image = _bin_and_composite(rows, st, need_vis_partial=False)
+      ctx.save_for_backward(pos, ls, rot, al, sh, indexes, T, proj, cam)
+      ctx.set_materialize_grads(False)
+      ctx.st, ctx.jac, ctx.grad_out, ctx.sh_out = st, None, grad_out, sh_out
+      ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype, feature.dtype)
+      ctx.mark_non_differentiable(indexes)
+      return image, rows[:, 0:6], rows[:, 6:7], indexes
+    frame = _lib.GsrFrameC(pos.data_ptr(), ls.data_ptr(), rot.data_ptr(), al.data_ptr(), sh.data_ptr(), N, K, W, H,
+                           T.data_ptr(), proj.data_ptr(), cam.data_ptr(), near, far, st.params,
+                           int(bool(want_pos_grad and K > 1)), int(st.want_median), int(st.compute_visibility),
+                           int(bool(st.needs_grad)), st.seg_pairs, st.seg_min, 0)
+    guesses, raw_guess, capacity = _pair_capacity(dev.index, N)
+    plan, res = _lib.GsrFramePlanC(), _lib.GsrFrameResultC()
+    timer = KERNEL_TIMER
+    while True:
+      frame.pair_capacity = capacity
+      _lib.check(lib.gsr_frame_plan(C.byref(frame), C.byref(plan)), "gsr_frame_plan")
+      out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
+      work = torch.empty(plan.work_bytes, dtype=torch.uint8, device=dev)
+      ev = timer.pair("composite_forward") if timer is not None else (None, None)
+      _lib.check(lib.gsr_frame_forward(C.byref(frame), C.byref(plan), C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(work.data_ptr()), C.byref(res), ev[0], ev[1], _stream()),
+                 "gsr_frame_forward")
+      del work                                   # scratch: the allocator may hand it on (stream order keeps it safe)
+      counts = _arena_view(out, plan.counts, (8,), torch.int32)
+      M, O, overflow = _start_readback(counts[:3])()       # the frame's only host sync, after everything is enqueued
+      if overflow or O < 0:      # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
+        raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
+      if O <= capacity:
+        break
+      if timer is not None:
+        timer.events["composite_forward"].pop()            # the frame is run again with exact sizes
+      capacity = O
+    guesses[dev.index] = min(max(O + O // 4 + 4096, raw_guess - raw_guess // 64), 0x7fffffff)   # grows at once, decays slowly
+    V = lambda off, shape, dtype=torch.float32: _arena_view(out, off, shape, dtype)
+    indexes = V(plan.indexes, (N,), torch.int64)[:M]
+    rows = V(plan.rows, (N, ROW_FLOATS))[:M]
+    st.M, st.O, st.rows = M, O, rows
+    st.screen_scale = V(plan.screen_scale, (N, 2))[:M]
+    st.order = V(res.order, (N,), torch.int32)
+    st.count, st.offsets = V(plan.count, (N,), torch.int32), V(plan.offsets, (N,), torch.int32)
+    st.sorted_splat = V(res.sorted_splat, (capacity,), torch.int32)
+    st.sorted_inst = V(res.sorted_inst, (capacity,), torch.int32)
+    st.tile_range = V(plan.tile_range, (num_tiles, 2), torch.int32)
+    keep = st.compute_visibility or st.needs_grad
+    st.vis_partial = V(plan.vis_partial, (capacity,)) if keep else None
+    st.pair_vis = V(plan.pair_vis, (capacity,)) if keep else None
+    st.final_T, st.last = V(plan.final_T, (H, W)), V(plan.last, (H, W), torch.int32)
+    st.median = V(plan.median, (H, W)) if st.want_median else None
+    st.visibility = V(plan.visibility, (N,))[:M]
+    st.prune_cost, st.split_score = V(plan.prune_cost, (N,))[:M], V(plan.split_score, (N,))[:M]
+    st.vis_capacity = capacity
+    if not st.compute_visibility:
+      st.visibility.zero_()
+    st.vis_ready = not (st.compute_visibility and st.needs_grad)    # without gradients the driver reduced it already
+    st.segments = _lib.GsrSegmentsC.from_buffer_copy(res.segments) if res.has_segments else None
+    st.segment_buffers = (out,)
+    image = V(plan.image, (H, W, 3))
     st.image = image.detach() if st.needs_grad else None
     ctx.save_for_backward(pos, ls, rot, al, sh, indexes, T, proj, cam)
     ctx.set_materialize_grads(False)       # unused outputs (gaussians2d / depth, usually) arrive as None
-    ctx.st, ctx.jac = st, (jac_full[:M] if jac_full is not None else None)
+    ctx.st, ctx.jac = st, (V(plan.jacobian, (N, 9))[:M] if plan.jacobian >= 0 else None)
     ctx.grad_out, ctx.sh_out = grad_out, sh_out
     ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype, feature.dtype)
     ctx.mark_non_differentiable(indexes)

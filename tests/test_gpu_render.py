@@ -525,10 +525,12 @@ def test_speculative_emit_and_early_colours_do_not_change_results():
     out = hip_render_and_grads(*scene, CFG, use_sh=True)
     return {k: out[k].clone() for k in keys}, out["num_overlaps"]
 
-  renderer._TLS.__dict__.pop("overlap_guess", None)             # no guess: the emit waits for the total
+  renderer._TLS.__dict__.pop("overlap_guess", None)             # no guess: the first frame starts from 4 pairs per row
   first_small, o_small = run(small)
   assert renderer._TLS.overlap_guess[0] >= o_small
-  first_large, o_large = run(large)                             # guess from the small frame is too small: emits again
+  renderer._TLS.overlap_guess[0] = o_small + o_small // 4 + 4096   # what a run of such small frames would have left
+  assert o_small + o_small // 4 + 4096 < 20000
+  first_large, o_large = run(large)                             # capacity from the small frames is too small: runs again
   assert o_large > o_small + o_small // 4 + 4096
   again_small, _ = run(small)                                   # generous guess: narrowed views of larger buffers
   again_large, _ = run(large)

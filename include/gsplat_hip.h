@@ -290,7 +290,7 @@ int gsr_unpack_grad_rows(const float* rows /* the forward rows [M,16] */, const 
  * scripts/test_split.py:30.)  The same launches as the single entry points above, chained with the two data-dependent
  * sizes of a frame left on the device: kernels run over the N scene rows and stop at the visible count M (counts[0]),
  * pair buffers hold `pair_capacity` pairs and every kernel reads the pair count O (counts[1]) on the device.  The host
- * reads counts[0..2] = [M, O, overflow flag] back afterwards; when O > pair_capacity the frame is run again with a
+ * receives counts[0..2] = [M, O, overflow flag] from the middle of the chain; when O > pair_capacity the frame is run again with a
  * larger capacity (nothing in the results depends on the capacity or on N as a bound).  C = 3 feature channels. */
 typedef struct GsrFrameC {
   const float* position;        /* [N,3] */
@@ -337,9 +337,13 @@ typedef struct GsrFrameResultC {
   int32_t has_segments;
 } GsrFrameResultC;
 int gsr_frame_plan(const GsrFrameC* frame_host, GsrFramePlanC* plan_out_host);
-/* event_k6_begin / event_k6_end: hipEvent_t recorded around the composite launch (bench.py's roofline leg), or NULL. */
+/* counts_host (pinned host memory, 3 words; may be NULL) receives [M, O, overflow] by an asynchronous copy issued right
+ * behind the scan that finalises them -- the rest of the chain is enqueued behind it -- and event_counts (hipEvent_t, may
+ * be NULL) is recorded after that copy: the caller waits on the event, not on the stream.
+ * event_k6_begin / event_k6_end: hipEvent_t recorded around the composite launch (bench.py's roofline leg), or NULL. */
 int gsr_frame_forward(const GsrFrameC* frame_host, const GsrFramePlanC* plan_host, void* out_arena, void* work_arena,
-                      GsrFrameResultC* result_out_host, void* event_k6_begin, void* event_k6_end, void* stream);
+                      GsrFrameResultC* result_out_host, uint32_t* counts_host, void* event_counts, void* event_k6_begin,
+                      void* event_k6_end, void* stream);
 
 /* ---- loss stage next to the path: fused SSIM, replaces the CUDA-only fused_ssim package
  *      the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462; trainer/evaluation.py:7,42) ------------ */

@@ -130,7 +130,7 @@ PROTOTYPES = {
     "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_frame_plan": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC)]),
     "gsr_frame_forward": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC), _p, _p, C.POINTER(GsrFrameResultC), _p,
-                                    _p, _p]),
+                                    _p, _p, _p, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "gsr_reduce_gradients": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p]),
     "gsr_unpack_grad_rows": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),

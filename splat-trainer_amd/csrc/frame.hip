@@ -129,7 +129,8 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
 }
 
 int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, void* work, GsrFrameResultC* res,
-                      void* event_k6_begin, void* event_k6_end, void* stream_) {
+                      uint32_t* counts_host, void* event_counts, void* event_k6_begin, void* event_k6_end,
+                      void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!f || !p || !out || !work || !res) return GSR_ERR_INVALID_ARGUMENT;
   if (f->N <= 0) return GSR_ERR_INVALID_ARGUMENT;          // an empty scene is the caller's blank frame
@@ -176,6 +177,15 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
   GSR_TRY(gsr_tile_count(rows, order, N, f->W, f->H, &f->params, count, hits, M_dev, stream_));
   GSR_TRY(gsr_exclusive_scan_u32_checked(count, offsets, N, O_dev, counts + 2, at<uint8_t>(work, p->scan_ws),
                                          (size_t)p->scan_ws_bytes, stream_));
+  // [M, O, overflow] are final here: their copy to the host goes in NOW, in the middle of the chain, so that the host --
+  // which needs them to shape the frame's tensors and goes on to enqueue the loss and the backward pass -- gets them
+  // while the device still has the emit, the tile sort and the composite ahead of it
+  if (counts_host) {
+    if (hipMemcpyAsync(counts_host, counts, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess)
+      return GSR_ERR_LAUNCH_FAILED;
+    if (event_counts && hipEventRecord(reinterpret_cast<hipEvent_t>(event_counts), stream) != hipSuccess)
+      return GSR_ERR_LAUNCH_FAILED;
+  }
   res->sorted_inst = res->sorted_splat = -1;
   float* image = at<float>(out, p->image);
   if (cap > 0) {

@@ -133,16 +133,24 @@ _TLS = threading.local()
 SPECULATE = os.environ.get("GSPLAT_HIP_NO_SPECULATION", "0") != "1"
 
 
+def _readback_slot(device):
+  """(pinned int32[8] landing buffer, event) of this thread for ``device``; the event has been recorded once so that
+  its native handle exists (native callers record it themselves)."""
+  pool = _TLS.__dict__.setdefault("readback", {})
+  key = device.index
+  if key not in pool:
+    event = torch.cuda.Event()
+    event.record(_lib.current_stream())
+    pool[key] = (torch.empty(8, dtype=torch.int32).pin_memory(), event)
+  return pool[key]
+
+
 def _start_readback(words: torch.Tensor):
   """Begins the device->host copy of a few int32 words on the current stream and returns ``wait() -> list``.
   The two sizes the path cannot know in advance (visible splats, tile overlaps) come back this way: whatever is
   enqueued between this call and ``wait()`` runs while the host blocks on the COPY's event, not on the stream, so the
   GPU does not idle through the host's round trip.  One pinned landing buffer + event per thread and device."""
-  pool = _TLS.__dict__.setdefault("readback", {})
-  key = words.device.index
-  if key not in pool:
-    pool[key] = (torch.empty(8, dtype=torch.int32).pin_memory(), torch.cuda.Event())
-  host, event = pool[key]
+  host, event = _readback_slot(words.device)
   n = words.numel()
   host[:n].copy_(words, non_blocking=True)
   event.record(_lib.current_stream())
@@ -647,12 +655,15 @@ class _FrameFn(torch.autograd.Function):
       out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
       work = torch.empty(plan.work_bytes, dtype=torch.uint8, device=dev)
       ev = timer.pair("composite_forward") if timer is not None else (None, None)
+      host, ready = _readback_slot(dev)
       _lib.check(lib.gsr_frame_forward(C.byref(frame), C.byref(plan), C.c_void_p(out.data_ptr()),
-                                       C.c_void_p(work.data_ptr()), C.byref(res), ev[0], ev[1], _stream()),
-                 "gsr_frame_forward")
+                                       C.c_void_p(work.data_ptr()), C.byref(res), C.c_void_p(host.data_ptr()),
+                                       C.c_void_p(ready.cuda_event), ev[0], ev[1], _stream()), "gsr_frame_forward")
       del work                                   # scratch: the allocator may hand it on (stream order keeps it safe)
-      counts = _arena_view(out, plan.counts, (8,), torch.int32)
-      M, O, overflow = _start_readback(counts[:3])()       # the frame's only host sync, after everything is enqueued
+      # the frame's only host wait: on the copy the driver issued right behind the scan, with the emit, the tile sort and
+      # the composite already enqueued behind it -- the device works on while the host shapes the tensors and moves on
+      ready.synchronize()
+      M, O, overflow = host[:3].tolist()
       if overflow or O < 0:      # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
         raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
       if O <= capacity:

@@ -176,6 +176,9 @@ def main():
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--settle", type=int, default=30,
+                  help="untimed steps before the timed region, INCLUDING --warmup (clocks and allocator settle; 0 = only "
+                       "the --warmup steps; profiles/r03_settle_trace.txt shows the per-step times either way)")
   ap.add_argument("--collective", default="sh_factor", choices=["reduce_scatter", "all_reduce", "sh_factor"],
                   help="gradient exchange at WORLD_SIZE > 1 (nothing is communicated on one GPU).  sh_factor (default, "
                        "distributed.DEFAULT_COLLECTIVE): all_reduce only the geometry gradients and all_gather the "
@@ -276,7 +279,7 @@ def main():
   # Untimed preparation: the device needs ~30 steps after an idle period before its clocks and the allocator reach a
   # steady state (per-step times fall monotonically from 1.30 to 1.12 ms over the first 25 steps on c2, BENCH_TRACE_STEPS=1),
   # so the W warm-up steps the caller asked for are preceded by enough extra untimed ones to make 30 in total.
-  prewarm = max(0, 30 - args.warmup)
+  prewarm = max(0, args.settle - args.warmup)
   for _ in range(prewarm + args.warmup):
     step()
   timer = renderer.KernelTimer()
@@ -357,6 +360,28 @@ def main():
             "frac_of_measured_copy_bw": (gbs / copy_gbs) if copy_gbs else None, "traffic": traffic,
             "algorithmic_bytes": alg_bytes, "avg_ms": ms}
 
+  # Useful arithmetic of the backward composite: contributing (pixel, splat) pairs x the fp32 operations one of them costs
+  # (K7's per-pixel body: ~45, an fma counted as 2), against the vector peak -- the honest counterpart of the issue-based
+  # figure below, which also counts the lanes masked to alpha = 0.  The pair count is the summed area of the ellipses
+  # {q <= min(9, 2 ln(255 opacity))} of the frame's splats: an upper estimate (it ignores saturated pixels and the image
+  # border).  Its ratio to the algorithmic bytes is the kernel's arithmetic intensity; above the chip's ridge
+  # (peak flops / peak bytes) the HBM roofline is not the binding one even at perfect efficiency.
+  with torch.no_grad():
+    g2d_, _, _ = sta.project_to_image(scene, batch[0], cfg)
+    qeff = torch.minimum(torch.full_like(g2d_[:, 5], cfg.gaussian_scale ** 2),
+                         2.0 * torch.log((g2d_[:, 5] / cfg.alpha_threshold).clamp_min(1e-20))).clamp_min(0.0)
+    px_pairs = float((math.pi * qeff / torch.sqrt((g2d_[:, 2] * g2d_[:, 4] - g2d_[:, 3] ** 2).clamp_min(1e-30))).sum())
+  FLOP_PER_PX_PAIR_BWD = 45.0
+  ridge = FP32_VECTOR_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+  def useful(ms):
+    tf = px_pairs * FLOP_PER_PX_PAIR_BWD / (ms * 1e-3) / 1e12 if ms == ms and ms > 0 else float("nan")
+    ai = px_pairs * FLOP_PER_PX_PAIR_BWD / max(alg_bytes_bwd, 1)
+    return {"contributing_pixel_pairs_estimate": px_pairs, "flop_per_pixel_pair": FLOP_PER_PX_PAIR_BWD,
+            "useful_fp32_tflops": tf, "useful_fp32_frac": tf / FP32_VECTOR_PEAK_TFLOPS,
+            "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+            "binding_roofline_at_perfect_efficiency": "fp32 vector" if ai > ridge else "hbm"}
+
   cameras_per_step = world
   value = N * cameras_per_step * args.steps / elapsed
   step_ms = 1e3 * elapsed / args.steps
@@ -371,6 +396,7 @@ def main():
                "hbm_copy_gbs_measured": copy_gbs,
                # K7 / K6 are bound by VALU issue, not by HBM: the second roofline states that bound
                "valu": valu_roofline("K7", "K7_bwd_C3", pmc, ms_bwd, O) if pmc else None,
+               "useful_fp32": useful(ms_bwd),
                "kernels": {
                    "K6 composite_fwd_kernel<3,vis> (alpha-composite forward, incl. heavy-tile passes)":
                        dict(line(alg_bytes_fwd, ms_fwd, traffic_of("K6")),
@@ -395,7 +421,7 @@ def main():
                                    f"dp{world} (camera-sharded, fused {args.collective} of {bucket.flat.numel() * 4 / 1e6:.0f} MB grads)"),
                    "parity": "parity unpinned by the reference (its rasterizer is an absent third-party package); "
                              "HIP vs this build's fp64 oracle is asserted by tests/ (-m gpu), observed errors in "
-                             "profiles/r02_parity_observed.txt"},
+                             "profiles/r03_parity_observed.txt"},
         "roofline": k7,
     }
     if check is not None:

@@ -181,7 +181,7 @@ int gsr_project_sh_forward(const float* position, const float* log_scaling, cons
 int gsr_project_backward_rows(const float* position, const float* log_scaling, const float* rotation_xyzw,
                               const float* alpha_logit, const int64_t* indexes, int64_t M, const int32_t* inverse,
                               int64_t N, const float* T_camera_world, const float* projection,
-                              const GsrRasterParamsC* params_host, const float* rows /* the forward rows [M,16] */,
+                              const GsrRasterParamsC* params_host, const float* rows /* unused (the conic is recomputed); may be NULL */,
                               const float* grad_rows, const float* dL_dgaussians2d_extra, const float* dL_ddepth,
                               const float* jacobian,
                               float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,

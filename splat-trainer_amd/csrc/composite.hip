@@ -148,7 +148,39 @@ template <int C>
 struct FwdPix {
   v2f T2[2], col2[2][3], med2[2];
   int lastc[4];
+  // row prefetch (GSR_K6_PREFETCH): packed splat ids of the pairs two blocks ahead / bits of a row one block ahead
+  uint32_t pf_rank, pf_bits, pf_sink;
 };
+
+// The walk fetches each pair's row through the scalar cache one pair ahead; at millions of splats the row table is far
+// larger than the L2s and that fetch comes from HBM (K6 on c3: 42 % of the wave cycles wait for data).  Every
+// GSR_K6_PREFETCH pairs the lanes therefore touch, with ordinary vector loads whose values are only folded into a sink
+// word one block later, the rows of the block after next -- by the time the scalar loads ask for them they sit in L2.
+#ifndef GSR_K6_PREFETCH
+#define GSR_K6_PREFETCH 32
+#endif
+template <int C>
+__device__ __forceinline__ void fwd_prefetch_init(FwdPix<C>& px, const uint32_t* __restrict__ sorted_rank,
+                                                  uint32_t begin, uint32_t pf_end, int lane) {
+  px.pf_bits = 0u; px.pf_sink = 0u; px.pf_rank = 0u;
+#if GSR_K6_PREFETCH
+  const uint32_t p = begin + GSR_K6_PREFETCH + (uint32_t)lane;
+  if (lane < GSR_K6_PREFETCH && p < pf_end) px.pf_rank = sorted_rank[p];
+#endif
+}
+template <int C>
+__device__ __forceinline__ void fwd_prefetch_step(FwdPix<C>& px, const float* __restrict__ rec,
+                                                  const uint32_t* __restrict__ sorted_rank, uint32_t i, uint32_t pf_end,
+                                                  int lane) {
+#if GSR_K6_PREFETCH
+  px.pf_sink |= px.pf_bits;                                   // issued a block ago: long arrived
+  const uint32_t p1 = i + GSR_K6_PREFETCH + (uint32_t)lane, p2 = p1 + GSR_K6_PREFETCH;
+  const bool mine = lane < GSR_K6_PREFETCH;
+  px.pf_bits = (mine && p1 < pf_end)
+                   ? __float_as_uint(rec[(size_t)GSR_ROW_FLOATS * (px.pf_rank & 0x3FFFFFFFu)]) : 0u;
+  px.pf_rank = (mine && p2 < pf_end) ? sorted_rank[p2] : 0u;
+#endif
+}
 
 // Front-to-back walk over list positions [begin, end) of one tile; `tile_start` makes the recorded last-contributor
 // index tile-relative.  A pixel is live while T >= T_eps.
@@ -157,12 +189,16 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
                                          const uint32_t* __restrict__ sorted_rank,
                                          const uint32_t* __restrict__ sorted_inst, uint32_t tile_start, uint32_t begin,
                                          uint32_t end, float fx0, float fy0, const GsrRasterParams& rp, int lane,
-                                         float* __restrict__ vis_partial, float* __restrict__ pair_vis) {
+                                         float* __restrict__ vis_partial, float* __restrict__ pair_vis,
+                                         uint32_t pf_end) {
   // lane 16r+15 ends up with the visibility total of pair (i + {0,2,1,3}[r]) of each group of four
   const uint32_t vis_slot = (uint32_t)(((lane >> 4) & 1) * 2 + (lane >> 5));
   if (begin >= end) return;
   Splat nxt = load_splat<C>(rec, sorted_rank, begin);
   for (uint32_t i = begin; i < end; i += 4) {
+#if GSR_K6_PREFETCH
+    if (((i - tile_start) & (GSR_K6_PREFETCH - 1)) == 0u) fwd_prefetch_step<C>(px, rec, sorted_rank, i, pf_end, lane);
+#endif
     float wq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -303,9 +339,10 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
 
   FwdPix<C> px;
   fwd_init<C>(px, px0, py0, W, H);
+  fwd_prefetch_init<C>(px, sorted_rank, start, end, lane);
   if (tseg == 0u) {
     fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, start, end, fx0, fy0, rp, lane, vis_partial,
-                             pair_vis);
+                             pair_vis, end);
   } else {
     // A long (but not heavy) tile is still walked by this one wave, but the walk pauses at the segment ends and leaves
     // a checkpoint -- (T, colour composited so far) per pixel, one 16-byte store each -- so that the backward pass can
@@ -315,7 +352,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
     for (uint32_t j = 0; j < tseg; ++j) {
       const uint32_t* d = seg.seg_desc + 4 * (size_t)(first + j);
       fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, d[1], d[2], fx0, fy0, rp, lane, vis_partial,
-                               pair_vis);
+                               pair_vis, end);
       float4* out = seg.seg_TC + 256 * (size_t)(first + j) + lane;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -329,6 +366,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
     }
   }
 
+  if ((px.pf_sink | px.pf_bits) == 0x7FC0FFEEu) final_T[0] = 0.f;   // never true (a quiet-NaN pattern no row holds): keeps the prefetch loads alive
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int x = px0 + 8 * (p & 1), y = py0 + 8 * (p >> 1);
@@ -368,6 +406,7 @@ __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restri
 
   FwdPix<C> px;
   fwd_init<C>(px, px0, py0, W, H);
+  fwd_prefetch_init<C>(px, sorted_rank, begin, end, lane);
   for (uint32_t s = first; s < sidx; ++s) {
     const float* P = seg.seg_P + 256 * (size_t)s + lane;
     px.T2[0] = px.T2[0] * (v2f){P[0], P[64]};
@@ -376,7 +415,7 @@ __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restri
   const bool alive[4] = {px.T2[0].x >= rp.T_eps, px.T2[0].y >= rp.T_eps, px.T2[1].x >= rp.T_eps, px.T2[1].y >= rp.T_eps};
   if (__ballot(alive[0] || alive[1] || alive[2] || alive[3]) != 0ull)
     fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, tile_range[2 * tile], begin, end, fx0, fy0, rp, lane,
-                             vis_partial, pair_vis);
+                             vis_partial, pair_vis, end);
   const size_t o = 256 * (size_t)sidx + lane;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {

@@ -163,7 +163,10 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
 constexpr int RS_THREADS = 256;
 constexpr int RS_MAX_BINS = 512;
 
-inline int rs_rounds_for(int64_t n) { return n < (4ll << 20) ? 4 : 16; }     // 1024 or 4096 pairs per block
+#ifndef GSR_RS_BIG_MIN
+#define GSR_RS_BIG_MIN (4ll << 20)
+#endif
+inline int rs_rounds_for(int64_t n) { return n < GSR_RS_BIG_MIN ? 4 : 16; }     // 1024 or 4096 pairs per block
 inline int rs_digit_bits(int bits) { return (bits + 8) / 9 < (bits + 7) / 8 ? 9 : 8; }
 
 template <int BITS>

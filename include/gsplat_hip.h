@@ -74,7 +74,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 19) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 20) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -256,7 +256,11 @@ int gsr_composite_forward(const float* rows /* [M,16] */, const uint32_t* sorted
                           const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                           const GsrRasterParamsC* params_host, float* image_out, float* final_T_out,
                           int32_t* last_out, float* median_depth_out, float* vis_partial_out, float* pair_vis_out,
-                          const GsrSegmentsC* segments_host /* or NULL */, void* stream);
+                          const GsrSegmentsC* segments_host /* or NULL */,
+                          int32_t prefetch_rows /* speed only: touch the rows 32-64 pairs ahead of the walk (pays once the
+                                                   row table has outgrown the caches: GSR_PREFETCH_MIN_ROWS) */,
+                          void* stream);
+#define GSR_PREFETCH_MIN_ROWS 1000000
 
 /* ---- K7 alpha-composite backward (per-pixel reverse walk) ----------------------------------------------- */
 /* partial_out [O,12]: written only for pairs with pair_vis > 0 (the others are never read). */

@@ -14,7 +14,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
+PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
 class GsrRasterParamsC(C.Structure):
@@ -109,7 +110,7 @@ PROTOTYPES = {
     "gsr_segment_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "gsr_segment_heavy_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p]),
-    "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _ps, _p]),
+    "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _ps, _i32, _p]),
     "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _ps, _p]),
     "gsr_opt_point_weights": (C.c_int, [_p, _p, _i64, _p, _p, _f, _f, _f, _f, _i32, _p, _p]),
     "gsr_opt_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f, _f, _f, _f, _f, _p]),

@@ -156,35 +156,36 @@ struct FwdPix {
 // larger than the L2s and that fetch comes from HBM (K6 on c3: 42 % of the wave cycles wait for data).  Every
 // GSR_K6_PREFETCH pairs the lanes therefore touch, with ordinary vector loads whose values are only folded into a sink
 // word one block later, the rows of the block after next -- by the time the scalar loads ask for them they sit in L2.
+// PF is chosen by the caller per frame: it pays once the row table has outgrown the caches (3M splats: K6 722 -> 656 us)
+// and costs a frame whose rows sit in L2 anyway (500k: 204 -> 226 us: two more SGPRs, one more loop branch).
 #ifndef GSR_K6_PREFETCH
 #define GSR_K6_PREFETCH 32
 #endif
-template <int C>
+template <int C, bool PF>
 __device__ __forceinline__ void fwd_prefetch_init(FwdPix<C>& px, const uint32_t* __restrict__ sorted_rank,
-                                                  uint32_t begin, uint32_t pf_end, int lane) {
+                                                  uint32_t tile_start, uint32_t begin, uint32_t pf_end, int lane) {
   px.pf_bits = 0u; px.pf_sink = 0u; px.pf_rank = 0u;
-#if GSR_K6_PREFETCH
-  const uint32_t p = begin + GSR_K6_PREFETCH + (uint32_t)lane;
+  if (!PF) return;
+  // the walk steps the prefetch at list positions that are multiples of the block length from the tile's start
+  const uint32_t first = tile_start + ((begin - tile_start + GSR_K6_PREFETCH - 1u) & ~(uint32_t)(GSR_K6_PREFETCH - 1));
+  const uint32_t p = first + GSR_K6_PREFETCH + (uint32_t)lane;
   if (lane < GSR_K6_PREFETCH && p < pf_end) px.pf_rank = sorted_rank[p];
-#endif
 }
 template <int C>
 __device__ __forceinline__ void fwd_prefetch_step(FwdPix<C>& px, const float* __restrict__ rec,
                                                   const uint32_t* __restrict__ sorted_rank, uint32_t i, uint32_t pf_end,
                                                   int lane) {
-#if GSR_K6_PREFETCH
   px.pf_sink |= px.pf_bits;                                   // issued a block ago: long arrived
   const uint32_t p1 = i + GSR_K6_PREFETCH + (uint32_t)lane, p2 = p1 + GSR_K6_PREFETCH;
   const bool mine = lane < GSR_K6_PREFETCH;
   px.pf_bits = (mine && p1 < pf_end)
                    ? __float_as_uint(rec[(size_t)GSR_ROW_FLOATS * (px.pf_rank & 0x3FFFFFFFu)]) : 0u;
   px.pf_rank = (mine && p2 < pf_end) ? sorted_rank[p2] : 0u;
-#endif
 }
 
 // Front-to-back walk over list positions [begin, end) of one tile; `tile_start` makes the recorded last-contributor
 // index tile-relative.  A pixel is live while T >= T_eps.
-template <int C, bool VIS, bool MEDIAN>
+template <int C, bool VIS, bool MEDIAN, bool PF>
 __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict__ rec,
                                          const uint32_t* __restrict__ sorted_rank,
                                          const uint32_t* __restrict__ sorted_inst, uint32_t tile_start, uint32_t begin,
@@ -196,9 +197,7 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
   if (begin >= end) return;
   Splat nxt = load_splat<C>(rec, sorted_rank, begin);
   for (uint32_t i = begin; i < end; i += 4) {
-#if GSR_K6_PREFETCH
-    if (((i - tile_start) & (GSR_K6_PREFETCH - 1)) == 0u) fwd_prefetch_step<C>(px, rec, sorted_rank, i, pf_end, lane);
-#endif
+    if (PF && ((i - tile_start) & (GSR_K6_PREFETCH - 1)) == 0u) fwd_prefetch_step<C>(px, rec, sorted_rank, i, pf_end, lane);
     float wq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -307,7 +306,7 @@ __device__ __forceinline__ void seg_alpha_pass(uint32_t sidx, const float* __res
   out[0] = P2[0].x; out[64] = P2[0].y; out[128] = P2[1].x; out[192] = P2[1].y;
 }
 
-template <int C, bool VIS, bool MEDIAN>
+template <int C, bool VIS, bool MEDIAN, bool PF>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restrict__ rec,
                                                            const uint32_t* __restrict__ sorted_rank,
                                                            const uint32_t* __restrict__ sorted_inst,
@@ -339,9 +338,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
 
   FwdPix<C> px;
   fwd_init<C>(px, px0, py0, W, H);
-  fwd_prefetch_init<C>(px, sorted_rank, start, end, lane);
+  fwd_prefetch_init<C, PF>(px, sorted_rank, start, start, end, lane);
   if (tseg == 0u) {
-    fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, start, end, fx0, fy0, rp, lane, vis_partial,
+    fwd_walk<C, VIS, MEDIAN, PF>(px, rec, sorted_rank, sorted_inst, start, start, end, fx0, fy0, rp, lane, vis_partial,
                              pair_vis, end);
   } else {
     // A long (but not heavy) tile is still walked by this one wave, but the walk pauses at the segment ends and leaves
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
     const uint32_t first = seg.tile_seg[2 * tile];
     for (uint32_t j = 0; j < tseg; ++j) {
       const uint32_t* d = seg.seg_desc + 4 * (size_t)(first + j);
-      fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, start, d[1], d[2], fx0, fy0, rp, lane, vis_partial,
+      fwd_walk<C, VIS, MEDIAN, PF>(px, rec, sorted_rank, sorted_inst, start, d[1], d[2], fx0, fy0, rp, lane, vis_partial,
                                pair_vis, end);
       float4* out = seg.seg_TC + 256 * (size_t)(first + j) + lane;
 #pragma unroll
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
     }
   }
 
-  if ((px.pf_sink | px.pf_bits) == 0x7FC0FFEEu) final_T[0] = 0.f;   // never true (a quiet-NaN pattern no row holds): keeps the prefetch loads alive
+  if (PF && (px.pf_sink | px.pf_bits) == 0x7FC0FFEEu) final_T[0] = 0.f;   // never true (a quiet-NaN pattern no row holds): keeps the prefetch loads alive
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int x = px0 + 8 * (p & 1), y = py0 + 8 * (p >> 1);
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
 
 // Pass C of a heavy tile: the forward walk over one segment, entered with T_in = product of the preceding segments'
 // products (taken in segment order).  Outputs go to the segment's own 256-pixel slots (lane-major: slot p*64 + lane).
-template <int C, bool VIS, bool MEDIAN>
+template <int C, bool VIS, bool MEDIAN, bool PF>
 __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restrict__ rec,
                                                            const uint32_t* __restrict__ sorted_rank,
                                                            const uint32_t* __restrict__ sorted_inst,
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restri
 
   FwdPix<C> px;
   fwd_init<C>(px, px0, py0, W, H);
-  fwd_prefetch_init<C>(px, sorted_rank, begin, end, lane);
+  fwd_prefetch_init<C, PF>(px, sorted_rank, tile_range[2 * tile], begin, end, lane);
   for (uint32_t s = first; s < sidx; ++s) {
     const float* P = seg.seg_P + 256 * (size_t)s + lane;
     px.T2[0] = px.T2[0] * (v2f){P[0], P[64]};
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(64) void seg_composite_kernel(const float* __restri
   }
   const bool alive[4] = {px.T2[0].x >= rp.T_eps, px.T2[0].y >= rp.T_eps, px.T2[1].x >= rp.T_eps, px.T2[1].y >= rp.T_eps};
   if (__ballot(alive[0] || alive[1] || alive[2] || alive[3]) != 0ull)
-    fwd_walk<C, VIS, MEDIAN>(px, rec, sorted_rank, sorted_inst, tile_range[2 * tile], begin, end, fx0, fy0, rp, lane,
+    fwd_walk<C, VIS, MEDIAN, PF>(px, rec, sorted_rank, sorted_inst, tile_range[2 * tile], begin, end, fx0, fy0, rp, lane,
                              vis_partial, pair_vis, end);
   const size_t o = 256 * (size_t)sidx + lane;
 #pragma unroll
@@ -875,7 +874,7 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
                           const uint32_t* tile_range, int32_t W, int32_t H, int32_t C,
                           const GsrRasterParamsC* params_host, float* image_out, float* final_T_out, int32_t* last_out,
                           float* median_depth_out, float* vis_partial_out, float* pair_vis_out,
-                          const GsrSegmentsC* segments_host, void* stream_) {
+                          const GsrSegmentsC* segments_host, int32_t prefetch_rows, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
   if (params_host->tile_size != 16 || C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
@@ -887,18 +886,23 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
   if (!seg_ok(segments_host, med)) return GSR_ERR_INVALID_ARGUMENT;
   const SegDev seg = to_segdev(segments_host);
   const int cap = segments_host ? (int)segments_host->heavy_capacity : 0;   // blocks of the heavy-tile passes
-#define GSR_LAUNCH_FWD(CC, VV, MM)                                                                                     \
+#define GSR_LAUNCH_FWD2(CC, VV, MM, PP)                                                                                \
   do {                                                                                                                 \
-    composite_fwd_kernel<CC, VV, MM><<<nt + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, tx, \
-                                                                  nt, rp, image_out, final_T_out, last_out,            \
-                                                                  median_depth_out, vis_partial_out, pair_vis_out,     \
-                                                                  seg);                                                \
+    composite_fwd_kernel<CC, VV, MM, PP><<<nt + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, \
+                                                                      tx, nt, rp, image_out, final_T_out, last_out,    \
+                                                                      median_depth_out, vis_partial_out, pair_vis_out, \
+                                                                      seg);                                            \
     if (cap) {                                                                                                         \
-      seg_composite_kernel<CC, VV, MM><<<cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, tx,    \
-                                                               nt, rp, vis_partial_out, pair_vis_out, seg);            \
+      seg_composite_kernel<CC, VV, MM, PP><<<cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H,    \
+                                                                   tx, nt, rp, vis_partial_out, pair_vis_out, seg);    \
       seg_combine_kernel<CC, MM><<<nt, 64, 0, stream>>>(W, H, tx, nt, image_out, final_T_out, last_out,                \
                                                         median_depth_out, seg);                                        \
     }                                                                                                                  \
+  } while (0)
+#define GSR_LAUNCH_FWD(CC, VV, MM)                 \
+  do {                                             \
+    if (prefetch_rows) GSR_LAUNCH_FWD2(CC, VV, MM, true); \
+    else GSR_LAUNCH_FWD2(CC, VV, MM, false);       \
   } while (0)
 #define GSR_DISPATCH_FWD(CC)                                       \
   do {                                                             \
@@ -912,6 +916,7 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
   else GSR_DISPATCH_FWD(3);
 #undef GSR_DISPATCH_FWD
 #undef GSR_LAUNCH_FWD
+#undef GSR_LAUNCH_FWD2
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -232,7 +232,8 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
       return GSR_ERR_LAUNCH_FAILED;
     GSR_TRY(gsr_composite_forward(rows, sorted_splat, sorted_inst, tile_range, f->W, f->H, 3, &f->params, image,
                                   at<float>(out, p->final_T), at<int32_t>(out, p->last), at<float>(out, p->median),
-                                  at<float>(out, p->vis_partial), at<float>(out, p->pair_vis), seg, stream_));
+                                  at<float>(out, p->vis_partial), at<float>(out, p->pair_vis), seg,
+                                  N >= GSR_PREFETCH_MIN_ROWS ? 1 : 0, stream_));
     if (event_k6_end && hipEventRecord(reinterpret_cast<hipEvent_t>(event_k6_end), stream) != hipSuccess)
       return GSR_ERR_LAUNCH_FAILED;
     if (f->compute_visibility && !f->needs_grad)

@@ -497,7 +497,8 @@ def _bin_and_composite(rows: torch.Tensor, st: _RasterState, need_vis_partial: b
     _lib.check(lib.gsr_composite_forward(_ptr(rows), _ptr(st.sorted_splat), _ptr(st.sorted_inst),
                                          _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
                                          _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
-                                         _ptr(st.pair_vis), _seg_ref(st), stream), "gsr_composite_forward")
+                                         _ptr(st.pair_vis), _seg_ref(st), 1 if M >= _lib.PREFETCH_MIN_ROWS else 0,
+                                         stream), "gsr_composite_forward")
     if timer is not None:
       timer.end("composite_forward")
     if st.compute_visibility and not st.needs_grad:

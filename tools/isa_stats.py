@@ -101,8 +101,9 @@ def find(meta: dict, *needles: str) -> str:
 def audit() -> dict:
   meta = kernels(compile_isa("composite.hip"))
   out = {}
-  picks = {"K7_bwd_C3": ("composite_bwd_kernelILi3E",), "K6_fwd_C3_vis": ("composite_fwd_kernelILi3ELb1ELb0E",),
-           "K6_segC_C3_vis": ("seg_composite_kernelILi3ELb1ELb0E",), "K6_combine_C3": ("seg_combine_kernelILi3ELb0E",)}
+  picks = {"K7_bwd_C3": ("composite_bwd_kernelILi3E",), "K6_fwd_C3_vis": ("composite_fwd_kernelILi3ELb1ELb0ELb0E",),
+           "K6_fwd_C3_vis_prefetch": ("composite_fwd_kernelILi3ELb1ELb0ELb1E",),
+           "K6_segC_C3_vis": ("seg_composite_kernelILi3ELb1ELb0ELb0E",), "K6_combine_C3": ("seg_combine_kernelILi3ELb0E",)}
   for label, needles in picks.items():
     k = meta[find(meta, *needles)]
     body = k["body"]

@@ -176,6 +176,10 @@ def main():
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--form", default="one_call", choices=["one_call", "three_call"],
+                  help="one_call (default): render_gaussians(use_sh=True), the fused node behind the native frame driver; "
+                       "three_call: project_to_image -> evaluate_sh_at -> render_projected, the call shape of "
+                       "MLPScene.render (mlp_scene.py:410-427) with the SH evaluation standing in for the colour MLP")
   ap.add_argument("--settle", type=int, default=30,
                   help="untimed steps before the timed region, INCLUDING --warmup (clocks and allocator settle; 0 = only "
                        "the --warmup steps; profiles/r03_settle_trace.txt shows the per-step times either way)")
@@ -256,7 +260,14 @@ def main():
 
   def render_backward(j, cam, grad_out, collector):
     with torch.enable_grad():
-      r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
+      if args.form == "three_call":
+        prefetch = {}
+        g2d, depth, idx = sta.project_to_image(scene, cam, cfg, grad_out=grad_out, prefetch=prefetch)
+        sh_out = collector if collector is not None else (grad_out.feature, grad_out.position, grad_out)
+        feats = sta.evaluate_sh_at(feature, position, idx, cam.camera_position, grad_out=sh_out)
+        r = sta.render_projected(idx, g2d, feats, depth, cam, cfg, _depth_order=prefetch.get("depth_order"))
+      else:
+        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
       loss = sta.clamped_mse_loss(r.image, target_image)      # = F.mse_loss(image.clamp(0, 1), target), trainer.py:472-475
       loss.backward()
     last["r"] = r
@@ -411,7 +422,8 @@ def main():
         "ms_per_step_min_max": [per_step_ms[0], per_step_ms[-1]],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, "
-                               f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on",
+                               f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on"
+                               + (", three-call form" if args.form == "three_call" else ""),
                    "gaussians": N, "visible": M, "tile_overlaps": O, "pixels": P, "cameras_per_step": cameras_per_step,
                    "parallelism": ("dp1 (one GPU: gradients accumulate in place, no collective)" if world == 1 else
                                    f"dp{world} (camera-sharded; two collectives per step, no host sync: all_reduce of "

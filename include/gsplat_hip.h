@@ -74,7 +74,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 20) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 21) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -295,7 +295,7 @@ int gsr_unpack_grad_rows(const float* rows /* the forward rows [M,16] */, const 
  * sizes of a frame left on the device: kernels run over the N scene rows and stop at the visible count M (counts[0]),
  * pair buffers hold `pair_capacity` pairs and every kernel reads the pair count O (counts[1]) on the device.  The host
  * receives counts[0..2] = [M, O, overflow flag] from the middle of the chain; when O > pair_capacity the frame is run again with a
- * larger capacity (nothing in the results depends on the capacity or on N as a bound).  C = 3 feature channels. */
+ * larger capacity (nothing in the results depends on the capacity or on N as a bound). */
 typedef struct GsrFrameC {
   const float* position;        /* [N,3] */
   const float* log_scaling;     /* [N,3] */
@@ -316,6 +316,14 @@ typedef struct GsrFrameC {
   int32_t needs_grad;           /* a backward pass will follow: per-pair visibility + checkpoints are kept */
   int32_t seg_pairs, seg_min_pairs;   /* RasterConfig.segment_pairs / segment_min_pairs */
   int64_t pair_capacity;
+  /* Projected mode (position == NULL): the K4..K6 half of the three-call form, render_projected(indexes, gaussians2d,
+   * features, depth, ...) (mlp_scene.py:418-419) -- the rows are packed from the caller's tensors, N is the exact number
+   * of splats (nothing is culled here), C their feature channels, counts[0] is not used. */
+  const float* gaussians2d;     /* [N,6] */
+  const float* depth;           /* [N]   */
+  const float* features;        /* [N,C] */
+  int32_t C;                    /* 1..3 (3 in the one-call form) */
+  const uint32_t* depth_order;  /* [N] or NULL: the depth order when the caller has it already (skips the depth sort) */
 } GsrFrameC;
 /* Byte offsets of the frame's buffers inside the two caller-owned arenas (-1: not present in this frame).  `out`:
  * everything the Rendering or the backward pass still needs after the forward pass; the first zero_bytes bytes are

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -37,7 +37,8 @@ class GsrFrameC(C.Structure):
               ("camera_pos", C.c_void_p), ("near_plane", C.c_float), ("far_plane", C.c_float),
               ("params", GsrRasterParamsC), ("want_jacobian", C.c_int32), ("want_median", C.c_int32),
               ("compute_visibility", C.c_int32), ("needs_grad", C.c_int32), ("seg_pairs", C.c_int32),
-              ("seg_min_pairs", C.c_int32), ("pair_capacity", C.c_int64)]
+              ("seg_min_pairs", C.c_int32), ("pair_capacity", C.c_int64), ("gaussians2d", C.c_void_p),
+              ("depth", C.c_void_p), ("features", C.c_void_p), ("C", C.c_int32), ("depth_order", C.c_void_p)]
 
 
 FRAME_PLAN_FIELDS = ("out_bytes", "work_bytes", "zero_begin", "zero_bytes", "prune_cost", "split_score", "counts",

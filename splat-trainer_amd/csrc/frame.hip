@@ -56,7 +56,9 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
   if (!f || !p) return GSR_ERR_INVALID_ARGUMENT;
   if (f->N < 0 || f->N >= (1ll << 30) || f->W <= 0 || f->H <= 0 || f->pair_capacity < 0 || f->pair_capacity > 0x7FFFFFFFll)
     return GSR_ERR_INVALID_ARGUMENT;
-  if (f->K != 1 && f->K != 4 && f->K != 9 && f->K != 16) return GSR_ERR_UNSUPPORTED;
+  const bool projected = f->position == nullptr;
+  if (!projected && f->K != 1 && f->K != 4 && f->K != 9 && f->K != 16) return GSR_ERR_UNSUPPORTED;
+  if (f->C < 1 || f->C > 3 || (!projected && f->C != 3)) return GSR_ERR_UNSUPPORTED;
   if (f->params.tile_size != 16) return GSR_ERR_UNSUPPORTED;
   memset(p, 0, sizeof(*p));
   const int64_t N = f->N, cap = f->pair_capacity;
@@ -72,12 +74,12 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
   p->tile_range = out.take(4 * 2 * T);
   p->vis_partial = vis_partial ? out.take(4 * cap) : -1;
   p->zero_bytes = out.at;
-  p->indexes = out.take(8 * N);
+  p->indexes = projected ? -1 : out.take(8 * N);
   p->rows = out.take(4 * GSR_ROW_FLOATS * N);
   p->screen_scale = out.take(4 * 2 * N);
-  p->jacobian = (f->want_jacobian && f->K > 1) ? out.take(4 * 9 * N) : -1;
+  p->jacobian = (!projected && f->want_jacobian && f->K > 1) ? out.take(4 * 9 * N) : -1;
   p->visibility = out.take(4 * N);
-  p->image = out.take(4 * 3 * P);
+  p->image = out.take(4 * f->C * P);
   p->final_T = out.take(4 * P);
   p->last = out.take(4 * P);
   p->median = f->want_median ? out.take(4 * P) : -1;
@@ -111,7 +113,7 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
   p->out_bytes = out.at;
 
   Cursor work;
-  p->cull_ws_bytes = (int64_t)gsr_cull_workspace_bytes(N);
+  p->cull_ws_bytes = projected ? 0 : (int64_t)gsr_cull_workspace_bytes(N);
   p->sort_ws_bytes = (int64_t)gsr_sort_workspace_bytes(N);
   p->scan_ws_bytes = (int64_t)gsr_scan_workspace_bytes(N);
   p->tsort_ws_bytes = (int64_t)gsr_sort_workspace_bytes(cap);
@@ -134,14 +136,18 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!f || !p || !out || !work || !res) return GSR_ERR_INVALID_ARGUMENT;
   if (f->N <= 0) return GSR_ERR_INVALID_ARGUMENT;          // an empty scene is the caller's blank frame
-  if (!f->position || !f->log_scaling || !f->rotation_xyzw || !f->alpha_logit || !f->sh_features || !f->T_camera_world ||
-      !f->projection || !f->camera_pos)
+  const bool projected = f->position == nullptr;
+  if (projected) {
+    if (!f->gaussians2d || !f->depth || !f->features) return GSR_ERR_INVALID_ARGUMENT;
+  } else if (!f->log_scaling || !f->rotation_xyzw || !f->alpha_logit || !f->sh_features || !f->T_camera_world ||
+             !f->projection || !f->camera_pos) {
     return GSR_ERR_INVALID_ARGUMENT;
+  }
   memset(res, 0, sizeof(*res));
   const int64_t N = f->N, cap = f->pair_capacity;
   const int tx = (f->W + 15) / 16, ty = (f->H + 15) / 16, T = tx * ty;
   uint32_t* counts = at<uint32_t>(out, p->counts);
-  uint32_t* M_dev = counts;
+  uint32_t* M_dev = projected ? nullptr : counts;          // projected mode: N is exact
   uint32_t* O_dev = counts + 1;
   int rc;
 #define GSR_TRY(call)          \
@@ -152,25 +158,34 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
 
   if (hipMemsetAsync(at<uint8_t>(out, p->zero_begin), 0, (size_t)p->zero_bytes, stream) != hipSuccess)
     return GSR_ERR_LAUNCH_FAILED;
-  int64_t* indexes = at<int64_t>(out, p->indexes);
   float* rows = at<float>(out, p->rows);
-  GSR_TRY(gsr_frustum_cull(f->position, N, f->T_camera_world, f->projection, f->W, f->H, f->near_plane, f->far_plane,
-                           f->params.margin_px, indexes, M_dev, at<uint8_t>(work, p->cull_ws), (size_t)p->cull_ws_bytes,
-                           stream_));
   uint32_t key_bias = 0, key_max = 0;
   GSR_TRY(gsr_depth_key_range(f->near_plane, f->far_plane, &key_bias, &key_max));
   uint32_t* keys_a = at<uint32_t>(work, p->keys_a);
-  GSR_TRY(gsr_project_sh_forward(f->position, f->log_scaling, f->rotation_xyzw, f->alpha_logit, f->sh_features, f->K,
-                                 indexes, N, f->T_camera_world, f->projection, f->camera_pos, &f->params, rows,
-                                 at<float>(out, p->screen_scale), at<float>(out, p->jacobian), M_dev, keys_a, key_bias,
-                                 key_max, stream_));
+  if (projected) {
+    GSR_TRY(gsr_pack_rows(f->gaussians2d, f->depth, f->features, N, f->C, rows, at<float>(out, p->screen_scale), stream_));
+    if (!f->depth_order) GSR_TRY(gsr_depth_keys(f->depth, N, key_bias, key_max, keys_a, stream_));
+  } else {
+    int64_t* indexes = at<int64_t>(out, p->indexes);
+    GSR_TRY(gsr_frustum_cull(f->position, N, f->T_camera_world, f->projection, f->W, f->H, f->near_plane, f->far_plane,
+                             f->params.margin_px, indexes, M_dev, at<uint8_t>(work, p->cull_ws),
+                             (size_t)p->cull_ws_bytes, stream_));
+    GSR_TRY(gsr_project_sh_forward(f->position, f->log_scaling, f->rotation_xyzw, f->alpha_logit, f->sh_features, f->K,
+                                   indexes, N, f->T_camera_world, f->projection, f->camera_pos, &f->params, rows,
+                                   at<float>(out, p->screen_scale), at<float>(out, p->jacobian), M_dev, keys_a, key_bias,
+                                   key_max, stream_));
+  }
   // depth order of the visible splats (stable: ties keep ascending index), keys written by the projection
   uint32_t* vals_a = at<uint32_t>(out, p->vals_a);
   uint32_t* vals_b = at<uint32_t>(out, p->vals_b);
-  GSR_TRY(gsr_sort_pairs_u32(keys_a, vals_a, at<uint32_t>(work, p->keys_b), vals_b, N, 1, 0, bit_length(key_max),
-                             at<uint8_t>(work, p->sort_ws), (size_t)p->sort_ws_bytes, M_dev, stream_));
-  res->order = rc == 1 ? p->vals_b : p->vals_a;
-  const uint32_t* order = rc == 1 ? vals_b : vals_a;
+  const uint32_t* order = f->depth_order;
+  res->order = -1;                                          // the caller's own array
+  if (!order) {
+    GSR_TRY(gsr_sort_pairs_u32(keys_a, vals_a, at<uint32_t>(work, p->keys_b), vals_b, N, 1, 0, bit_length(key_max),
+                               at<uint8_t>(work, p->sort_ws), (size_t)p->sort_ws_bytes, M_dev, stream_));
+    res->order = rc == 1 ? p->vals_b : p->vals_a;
+    order = rc == 1 ? vals_b : vals_a;
+  }
   uint32_t* count = at<uint32_t>(out, p->count);
   uint32_t* offsets = at<uint32_t>(out, p->offsets);
   uint32_t* hits = at<uint32_t>(work, p->tile_hits);
@@ -230,7 +245,7 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
     }
     if (event_k6_begin && hipEventRecord(reinterpret_cast<hipEvent_t>(event_k6_begin), stream) != hipSuccess)
       return GSR_ERR_LAUNCH_FAILED;
-    GSR_TRY(gsr_composite_forward(rows, sorted_splat, sorted_inst, tile_range, f->W, f->H, 3, &f->params, image,
+    GSR_TRY(gsr_composite_forward(rows, sorted_splat, sorted_inst, tile_range, f->W, f->H, f->C, &f->params, image,
                                   at<float>(out, p->final_T), at<int32_t>(out, p->last), at<float>(out, p->median),
                                   at<float>(out, p->vis_partial), at<float>(out, p->pair_vis), seg,
                                   N >= GSR_PREFETCH_MIN_ROWS ? 1 : 0, stream_));

@@ -300,7 +300,8 @@ class _RasterState:
   __slots__ = ("M", "O", "C", "W", "H", "params", "rows", "order", "count", "offsets", "sorted_splat",
                "sorted_inst", "tile_range", "vis_partial", "pair_vis", "final_T", "last", "median", "visibility",
                "prune_cost", "split_score", "screen_scale", "want_median", "compute_visibility", "needs_grad",
-               "segments", "segment_buffers", "seg_pairs", "seg_min", "image", "key_range", "vis_ready", "vis_capacity")
+               "segments", "segment_buffers", "seg_pairs", "seg_min", "image", "key_range", "vis_ready", "vis_capacity",
+               "near_far")
 
   def materialize_visibility(self) -> torch.Tensor:
     """points.visibility = per-splat sum of the forward pass's per-pair partials.  A frame that is back-propagated gets
@@ -355,173 +356,24 @@ def _launch_depth_order(depth: Optional[torch.Tensor], M: int, key_range, keys: 
   return vals_b if where == 1 else vals_a
 
 
-def _plan_segments(st: "_RasterState", num_tiles: int, pairs: int, pairs_dev: Optional[torch.Tensor], dev, stream,
-                   seg_total: torch.Tensor):
-  """List segmentation (composite.hip): tiles longer than the frame's segment length are cut into segments; returns the
-  GsrSegmentsC the composite calls take, or None when switched off.  ``pairs`` is the frame's pair count, or -- with
-  ``pairs_dev``, the device word holding the count -- only an upper bound on it: the tables are then sized for any
-  count up to the bound and the plan kernel reads the count itself.  ``seg_total``: two zero-initialised device words (the
-  plan kernel's tiles reserve their segment slots on it)."""
-  st.segment_buffers = None
-  if st.seg_pairs == 0:
-    return None
-  lib = _lib.load()
-  grads = int(bool(st.needs_grad))
-  cap = int(lib.gsr_segment_capacity(pairs, 0 if pairs_dev is None else 1, st.seg_pairs, st.seg_min, num_tiles, grads))
-  if cap <= 0:
-    return None
-  bound = 0 if pairs_dev is None else 1
-  heavy_cap = min(cap, int(lib.gsr_segment_heavy_capacity(pairs, bound, st.seg_pairs, st.seg_min, num_tiles, grads)))
-  # [tile table (2 per tile) | compact list of the heavy tiles' segments | segment descriptors (4 per segment)]
-  tables = torch.empty(2 * num_tiles + heavy_cap + 4 * cap, dtype=torch.int32, device=dev)
-  tile_seg, seg_desc = tables[:2 * num_tiles + heavy_cap], tables[2 * num_tiles + heavy_cap:]
-  _lib.check(lib.gsr_segment_plan(_ptr(st.tile_range), num_tiles, st.seg_pairs, st.seg_min, grads, pairs, _ptr(pairs_dev),
-                                  cap, heavy_cap, _ptr(tile_seg), _ptr(seg_desc), _ptr(seg_total), stream),
-             "gsr_segment_plan")
-  planes = 5 + (1 if st.want_median else 0)                       # (T, c0, c1, c2) interleaved + alpha products (+ median)
-  pix = torch.empty(planes * cap * 256, dtype=torch.float32, device=dev)
-  seg_last = torch.empty(cap * 256, dtype=torch.int32, device=dev)
-  seg_TC, seg_P = pix[:4 * cap * 256], pix[4 * cap * 256:5 * cap * 256]
-  seg_med = pix[5 * cap * 256:] if st.want_median else None
-  st.segment_buffers = (tables, pix, seg_last, seg_total)           # kept alive until backward has run
-  return _lib.GsrSegmentsC(tile_seg.data_ptr(), seg_desc.data_ptr(), seg_total.data_ptr(), cap, heavy_cap, seg_P.data_ptr(),
-                           seg_TC.data_ptr(), seg_last.data_ptr(),
-                           seg_med.data_ptr() if seg_med is not None else None)
-
-
 def _seg_ref(st: "_RasterState"):
   return C.byref(st.segments) if st.segments is not None else None
 
 
-def _bin_and_composite(rows: torch.Tensor, st: _RasterState, need_vis_partial: bool,
-                       order: Optional[torch.Tensor] = None, depth: Optional[torch.Tensor] = None) -> torch.Tensor:
-  """K4 -> K5 -> K6 over the packed (M,16) rows (``st.screen_scale`` is already set by whoever made the rows).
-  ``order``: the depth order when it has been enqueued already; otherwise it is formed here from ``depth`` (M,)."""
-  lib = _lib.load()
-  dev = rows.device
+def _blank_frame(st: _RasterState, dev) -> torch.Tensor:
+  """The frame of an empty splat list (M = 0): colour 0, transmittance 1, no per-point outputs."""
   M, C_, W, H = st.M, st.C, st.W, st.H
-  stream = _stream()
-  tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
-  num_tiles = tiles_x * tiles_y
   st.O = 0
-
-  def heuristics(buf):
-    st.prune_cost, st.split_score = buf[0], buf[1]               # zero until backward fills them in place
-
-  def blank():
-    st.final_T = torch.ones(H, W, dtype=torch.float32, device=dev)
-    st.last = torch.zeros(H, W, dtype=torch.int32, device=dev)
-    st.median = torch.zeros(H, W, dtype=torch.float32, device=dev) if st.want_median else None
-    st.visibility = torch.zeros(M, dtype=torch.float32, device=dev)
-    st.vis_ready = True
-    return torch.zeros(H, W, C_, dtype=torch.float32, device=dev)
-
-  if M == 0:
-    heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))
-    st.screen_scale = torch.zeros(0, 2, dtype=torch.float32, device=dev)
-    return blank()
-  st.rows = rows
-
-  # depth order of the M splats (stable: ties keep ascending index); project_to_image may already have enqueued it
-  st.order = order if order is not None else _launch_depth_order(depth, M, st.key_range)
-
-  # per-splat tile counts (the one gather through the depth order: a 64-byte row per splat)
-  st.count = _u32(M, dev)
-  st.offsets = _u32(M, dev)
-  tile_hits = torch.empty(M, 4, dtype=torch.int32, device=dev)   # K4 count -> emit: the counted tiles of every splat
-  # Everything that must start at zero comes out of ONE zero-filled allocation (one fill launch per frame): the
-  # heuristics, the tile ranges, the segment counter, [number of overlaps, overflow flag] and the per-pair visibility.
-  # Its size depends on the pair count, which is only guessed at this point (see below); a frame without a guess, or
-  # one that outgrows it, pays a second fill.
-  guesses = _TLS.__dict__.setdefault("overlap_guess", {})
-  raw_guess = guesses.get(dev.index, 0) if SPECULATE else 0
-  # the capacity moves in steps of 1/16 of its power of two: while the (slowly decaying) guess stays inside a step the
-  # O-sized buffers keep their sizes from frame to frame and the caching allocator hands the same blocks back
-  step = 1 << max(raw_guess.bit_length() - 5, 0)
-  guess = min((raw_guess + step - 1) // step * step, 0x7fffffff) if raw_guess > 0 else 0
-  fixed_zeros = 2 * M + 2 * num_tiles + 4                        # ... + capacity floats of per-pair visibility
-
-  def zero_block(capacity):
-    return torch.zeros(fixed_zeros + (capacity if need_vis_partial else 0), dtype=torch.float32, device=dev)
-
-  zeros_guess = zero_block(guess) if guess > 0 else None
-  total = (zeros_guess[fixed_zeros - 2:fixed_zeros].view(torch.int32) if zeros_guess is not None else
-           torch.zeros(2, dtype=torch.int32, device=dev))         # [number of overlaps, overflow flag]
-  _lib.check(lib.gsr_tile_count(_ptr(rows), _ptr(st.order), M, W, H, C.byref(st.params), _ptr(st.count), _ptr(tile_hits),
-                                None, stream), "gsr_tile_count")
-  scan_bytes = lib.gsr_scan_workspace_bytes(M)
-  scan_ws = torch.empty(scan_bytes, dtype=torch.uint8, device=dev)
-  _lib.check(lib.gsr_exclusive_scan_u32_checked(_ptr(st.count), _ptr(st.offsets), M, _ptr(total), _ptr(total[1:]),
-                                                _ptr(scan_ws), scan_bytes, stream), "gsr_exclusive_scan_u32_checked")
-  wait = _start_readback(total)  # host "sync" #2: the number of (tile, splat) overlaps
-
-  def rasterize(capacity: int, pairs_dev: Optional[torch.Tensor], zeros: Optional[torch.Tensor] = None):
-    """K4 emit -> K5 tile sort -> tile ranges -> segment plan -> K6 (+ per-splat visibility) into buffers holding
-    ``capacity`` pairs.  With ``pairs_dev`` (the device word with the pair count) the capacity is only a bound: every
-    kernel that needs the count reads it there, so the whole chain is enqueued before the count has reached the host."""
-    tkeys_a, trank_a = _u32(capacity, dev), _u32(capacity, dev)
-    _lib.check(lib.gsr_tile_emit(_ptr(rows), _ptr(st.order), _ptr(st.offsets), _ptr(tile_hits), M, W, H, C.byref(st.params),
-                                 _ptr(tkeys_a), _ptr(trank_a), capacity, None, stream), "gsr_tile_emit")
-    tkeys_b, tvals_a, tvals_b, trank_b = _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev), _u32(capacity, dev)
-    if zeros is None:
-      zeros = zero_block(capacity)
-    heuristics(zeros[:2 * M].view(2, M))
-    # K6 writes every pixel of every tile (an empty tile writes colour 0, T 1, last 0): no zero-fills needed
-    image = torch.empty(H, W, C_, dtype=torch.float32, device=dev)
-    st.final_T = torch.empty(H, W, dtype=torch.float32, device=dev)
-    st.last = torch.empty(H, W, dtype=torch.int32, device=dev)
-    st.median = torch.empty(H, W, dtype=torch.float32, device=dev) if st.want_median else None
-    st.visibility = (torch.empty if st.compute_visibility else torch.zeros)(M, dtype=torch.float32, device=dev)
-    st.vis_ready, st.vis_capacity = not st.compute_visibility, capacity
-
-    # stable-sort the pairs by tile id, find per-tile ranges
-    tile_bits = max(1, int(math.ceil(math.log2(num_tiles)))) if num_tiles > 1 else 1
-    tsort_bytes = lib.gsr_sort_workspace_bytes(capacity)
-    tsort_ws = torch.empty(tsort_bytes, dtype=torch.uint8, device=dev)
-    # values: instance id (implicit 0..O-1) and splat id (+ half mask) travel with the tile key
-    where = _lib.check(lib.gsr_sort_pairs2_u32(_ptr(tkeys_a), _ptr(tvals_a), _ptr(trank_a), _ptr(tkeys_b), _ptr(tvals_b),
-                                               _ptr(trank_b), capacity, 1, 0, tile_bits, _ptr(tsort_ws), tsort_bytes,
-                                               _ptr(pairs_dev), stream), "gsr_sort_pairs2_u32(tile)")
-    sorted_keys, st.sorted_inst, st.sorted_splat = (tkeys_b, tvals_b, trank_b) if where == 1 else (tkeys_a, tvals_a, trank_a)
-    st.tile_range = zeros[2 * M:2 * M + 2 * num_tiles].view(torch.int32).view(num_tiles, 2)
-    _lib.check(lib.gsr_tile_ranges(_ptr(sorted_keys), capacity, num_tiles, _ptr(st.tile_range), _ptr(pairs_dev), stream),
-               "gsr_tile_ranges")
-
-    st.vis_partial = zeros[fixed_zeros:] if need_vis_partial else None
-    st.pair_vis = torch.empty(capacity, dtype=torch.float32, device=dev) if need_vis_partial else None
-    st.segments = _plan_segments(st, num_tiles, capacity, pairs_dev, dev, stream,
-                                 zeros[2 * M + 2 * num_tiles:2 * M + 2 * num_tiles + 2].view(torch.int32))
-    timer = KERNEL_TIMER
-    if timer is not None:
-      timer.begin("composite_forward")
-    _lib.check(lib.gsr_composite_forward(_ptr(rows), _ptr(st.sorted_splat), _ptr(st.sorted_inst),
-                                         _ptr(st.tile_range), W, H, C_, C.byref(st.params), _ptr(image),
-                                         _ptr(st.final_T), _ptr(st.last), _ptr(st.median), _ptr(st.vis_partial),
-                                         _ptr(st.pair_vis), _seg_ref(st), 1 if M >= _lib.PREFETCH_MIN_ROWS else 0,
-                                         stream), "gsr_composite_forward")
-    if timer is not None:
-      timer.end("composite_forward")
-    if st.compute_visibility and not st.needs_grad:
-      st.materialize_visibility()       # no backward pass will deliver it: reduce the per-pair partials now
-    return image
-
-  # The O-sized buffers are sized from the totals of the frames before and the whole chain is enqueued BEFORE this frame's
-  # total is known: the GPU never waits for the host's round trip, and by the time the host looks at the total (after
-  # the composite launch) it has long arrived.  Only a frame that outgrows the guess is run again, with exact sizes.
-  # Nothing in the result depends on the guess: kernels take the pair count from the device and ignore the slack.
-  image = rasterize(guess, total[:1], zeros_guess) if guess > 0 else None
-  O, overflow = wait()
-  if overflow or O < 0:          # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
-    raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
-  st.O = O
-  guesses[dev.index] = min(max(O + O // 4 + 4096, raw_guess - raw_guess // 64), 0x7fffffff)   # grows at once, decays slowly
-  if O == 0:
-    st.segments, st.segment_buffers = None, None
-    heuristics(torch.zeros(2, M, dtype=torch.float32, device=dev))
-    return blank()
-  if image is None or O > guess:
-    image = rasterize(O, None)
-  return image
+  st.rows = torch.empty(0, ROW_FLOATS, dtype=torch.float32, device=dev)
+  st.prune_cost, st.split_score = torch.zeros(2, M, dtype=torch.float32, device=dev).unbind(0)
+  st.screen_scale = torch.zeros(0, 2, dtype=torch.float32, device=dev)
+  st.final_T = torch.ones(H, W, dtype=torch.float32, device=dev)
+  st.last = torch.zeros(H, W, dtype=torch.int32, device=dev)
+  st.median = torch.zeros(H, W, dtype=torch.float32, device=dev) if st.want_median else None
+  st.visibility = torch.zeros(M, dtype=torch.float32, device=dev)
+  st.vis_ready = True
+  st.segments, st.segment_buffers = None, None
+  return torch.zeros(H, W, C_, dtype=torch.float32, device=dev)
 
 
 def _composite_backward_rows(st: _RasterState, d_image: Optional[torch.Tensor], dev) -> torch.Tensor:
@@ -566,14 +418,17 @@ class _RasterFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, g2d, feats, depth, st: _RasterState, order):
-    lib = _lib.load()
     g, f, d = _f32c(g2d), _f32c(feats), _f32c(depth).reshape(-1)
-    rows = torch.empty(st.M, ROW_FLOATS, dtype=torch.float32, device=g.device)
-    st.screen_scale = torch.empty(st.M, 2, dtype=torch.float32, device=g.device)
-    _lib.check(lib.gsr_pack_rows(_ptr(g), _ptr(d), _ptr(f), st.M, st.C, _ptr(rows), _ptr(st.screen_scale), _stream()),
-               "gsr_pack_rows")
-    image = _bin_and_composite(rows, st, need_vis_partial=st.compute_visibility or st.needs_grad, order=order, depth=d)
-    st.image = image.detach() if st.needs_grad else None     # segment blocks of the backward pass need the final colour
+    if st.M == 0:
+      image = _blank_frame(st, g.device)
+    else:
+      # the native frame driver in projected mode: pack -> depth sort -> K4 -> K5 -> K6 behind one call
+      st.order = order
+      frame = _lib.GsrFrameC(None, None, None, None, None, st.M, 1, st.W, st.H, None, None, None, st.near_far[0],
+                             st.near_far[1], st.params, 0, int(st.want_median), int(st.compute_visibility),
+                             int(bool(st.needs_grad)), st.seg_pairs, st.seg_min, 0, g.data_ptr(), d.data_ptr(),
+                             f.data_ptr(), st.C, order.data_ptr() if order is not None else None)
+      _, _, _, image = _run_frame(frame, st, g.device, st.M, projected=True)
     ctx.st = st
     ctx.in_dtypes = (g2d.dtype, feats.dtype)      # e.g. fp16 colours from an autocast MLP (mlp_scene.py:362)
     return image
@@ -615,6 +470,69 @@ def _pair_capacity(dev_index, N: int):
   return guesses, raw, min((raw + step - 1) // step * step, 0x7fffffff)
 
 
+def _run_frame(frame: "_lib.GsrFrameC", st: _RasterState, dev, rows_bound: int, projected: bool):
+  """Enqueues one frame through the native driver (csrc/frame.hip) and fills ``st`` with views of its output arena.
+  ``rows_bound``: the scene's N (one-call form: the visible count M comes back from the device) or the exact number of
+  splats (projected mode).  Returns (out arena, plan, M)."""
+  lib = _lib.load()
+  guesses, raw_guess, capacity = _pair_capacity(dev.index, rows_bound)
+  plan, res = _lib.GsrFramePlanC(), _lib.GsrFrameResultC()
+  timer = KERNEL_TIMER
+  N, W, H, C_ = rows_bound, st.W, st.H, st.C
+  while True:
+    frame.pair_capacity = capacity
+    _lib.check(lib.gsr_frame_plan(C.byref(frame), C.byref(plan)), "gsr_frame_plan")
+    out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
+    work = torch.empty(plan.work_bytes, dtype=torch.uint8, device=dev)
+    ev = timer.pair("composite_forward") if timer is not None else (None, None)
+    host, ready = _readback_slot(dev)
+    _lib.check(lib.gsr_frame_forward(C.byref(frame), C.byref(plan), C.c_void_p(out.data_ptr()),
+                                     C.c_void_p(work.data_ptr()), C.byref(res), C.c_void_p(host.data_ptr()),
+                                     C.c_void_p(ready.cuda_event), ev[0], ev[1], _stream()), "gsr_frame_forward")
+    del work                                   # scratch: the allocator may hand it on (stream order keeps it safe)
+    # the frame's only host wait: on the copy the driver issued right behind the scan, with the emit, the tile sort and
+    # the composite already enqueued behind it -- the device works on while the host shapes the tensors and moves on
+    ready.synchronize()
+    M, O, overflow = host[:3].tolist()
+    if overflow or O < 0:      # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
+      raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
+    if O <= capacity:
+      break
+    if timer is not None:
+      timer.events["composite_forward"].pop()            # the frame is run again with exact sizes
+    capacity = O
+  guesses[dev.index] = min(max(O + O // 4 + 4096, raw_guess - raw_guess // 64), 0x7fffffff)   # grows at once, decays slowly
+  if projected:
+    M = N
+  num_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+  V = lambda off, shape, dtype=torch.float32: _arena_view(out, off, shape, dtype)
+  st.M, st.O = M, O
+  st.rows = V(plan.rows, (N, ROW_FLOATS))[:M]
+  st.screen_scale = V(plan.screen_scale, (N, 2))[:M]
+  if res.order >= 0:
+    st.order = V(res.order, (N,), torch.int32)
+  st.count, st.offsets = V(plan.count, (N,), torch.int32), V(plan.offsets, (N,), torch.int32)
+  st.sorted_splat = V(res.sorted_splat, (capacity,), torch.int32)
+  st.sorted_inst = V(res.sorted_inst, (capacity,), torch.int32)
+  st.tile_range = V(plan.tile_range, (num_tiles, 2), torch.int32)
+  keep = st.compute_visibility or st.needs_grad
+  st.vis_partial = V(plan.vis_partial, (capacity,)) if keep else None
+  st.pair_vis = V(plan.pair_vis, (capacity,)) if keep else None
+  st.final_T, st.last = V(plan.final_T, (H, W)), V(plan.last, (H, W), torch.int32)
+  st.median = V(plan.median, (H, W)) if st.want_median else None
+  st.visibility = V(plan.visibility, (N,))[:M]
+  st.prune_cost, st.split_score = V(plan.prune_cost, (N,))[:M], V(plan.split_score, (N,))[:M]
+  st.vis_capacity = capacity
+  if not st.compute_visibility:
+    st.visibility.zero_()
+  st.vis_ready = not (st.compute_visibility and st.needs_grad)    # without gradients the driver reduced it already
+  st.segments = _lib.GsrSegmentsC.from_buffer_copy(res.segments) if res.has_segments else None
+  st.segment_buffers = (out,)
+  image = V(plan.image, (H, W, C_))
+  st.image = image.detach() if st.needs_grad else None
+  return out, plan, M, image
+
+
 class _FrameFn(torch.autograd.Function):
   """The one-call form with SH colours as ONE autograd node.  Forward: the native frame driver (csrc/frame.hip) enqueues
   K1 cull -> fused K2 + K3 (one packed 64-byte row per visible splat) -> K4 -> K5 -> K6 behind a single call, with the
@@ -634,9 +552,9 @@ class _FrameFn(torch.autograd.Function):
     num_tiles = ((W + 15) // 16) * ((H + 15) // 16)
     if N == 0:
       indexes = torch.empty(0, dtype=torch.int64, device=dev)
-      rows = torch.empty(0, ROW_FLOATS, dtype=torch.float32, device=dev)
       st.M = 0
-      image = _bin_and_composite(rows, st, need_vis_partial=False)
+      image = _blank_frame(st, dev)
+      rows = st.rows
       ctx.save_for_backward(pos, ls, rot, al, sh, indexes, T, proj, cam)
       ctx.set_materialize_grads(False)
       ctx.st, ctx.jac, ctx.grad_out, ctx.sh_out = st, None, grad_out, sh_out
@@ -646,61 +564,13 @@ class _FrameFn(torch.autograd.Function):
     frame = _lib.GsrFrameC(pos.data_ptr(), ls.data_ptr(), rot.data_ptr(), al.data_ptr(), sh.data_ptr(), N, K, W, H,
                            T.data_ptr(), proj.data_ptr(), cam.data_ptr(), near, far, st.params,
                            int(bool(want_pos_grad and K > 1)), int(st.want_median), int(st.compute_visibility),
-                           int(bool(st.needs_grad)), st.seg_pairs, st.seg_min, 0)
-    guesses, raw_guess, capacity = _pair_capacity(dev.index, N)
-    plan, res = _lib.GsrFramePlanC(), _lib.GsrFrameResultC()
-    timer = KERNEL_TIMER
-    while True:
-      frame.pair_capacity = capacity
-      _lib.check(lib.gsr_frame_plan(C.byref(frame), C.byref(plan)), "gsr_frame_plan")
-      out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
-      work = torch.empty(plan.work_bytes, dtype=torch.uint8, device=dev)
-      ev = timer.pair("composite_forward") if timer is not None else (None, None)
-      host, ready = _readback_slot(dev)
-      _lib.check(lib.gsr_frame_forward(C.byref(frame), C.byref(plan), C.c_void_p(out.data_ptr()),
-                                       C.c_void_p(work.data_ptr()), C.byref(res), C.c_void_p(host.data_ptr()),
-                                       C.c_void_p(ready.cuda_event), ev[0], ev[1], _stream()), "gsr_frame_forward")
-      del work                                   # scratch: the allocator may hand it on (stream order keeps it safe)
-      # the frame's only host wait: on the copy the driver issued right behind the scan, with the emit, the tile sort and
-      # the composite already enqueued behind it -- the device works on while the host shapes the tensors and moves on
-      ready.synchronize()
-      M, O, overflow = host[:3].tolist()
-      if overflow or O < 0:      # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
-        raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
-      if O <= capacity:
-        break
-      if timer is not None:
-        timer.events["composite_forward"].pop()            # the frame is run again with exact sizes
-      capacity = O
-    guesses[dev.index] = min(max(O + O // 4 + 4096, raw_guess - raw_guess // 64), 0x7fffffff)   # grows at once, decays slowly
-    V = lambda off, shape, dtype=torch.float32: _arena_view(out, off, shape, dtype)
-    indexes = V(plan.indexes, (N,), torch.int64)[:M]
-    rows = V(plan.rows, (N, ROW_FLOATS))[:M]
-    st.M, st.O, st.rows = M, O, rows
-    st.screen_scale = V(plan.screen_scale, (N, 2))[:M]
-    st.order = V(res.order, (N,), torch.int32)
-    st.count, st.offsets = V(plan.count, (N,), torch.int32), V(plan.offsets, (N,), torch.int32)
-    st.sorted_splat = V(res.sorted_splat, (capacity,), torch.int32)
-    st.sorted_inst = V(res.sorted_inst, (capacity,), torch.int32)
-    st.tile_range = V(plan.tile_range, (num_tiles, 2), torch.int32)
-    keep = st.compute_visibility or st.needs_grad
-    st.vis_partial = V(plan.vis_partial, (capacity,)) if keep else None
-    st.pair_vis = V(plan.pair_vis, (capacity,)) if keep else None
-    st.final_T, st.last = V(plan.final_T, (H, W)), V(plan.last, (H, W), torch.int32)
-    st.median = V(plan.median, (H, W)) if st.want_median else None
-    st.visibility = V(plan.visibility, (N,))[:M]
-    st.prune_cost, st.split_score = V(plan.prune_cost, (N,))[:M], V(plan.split_score, (N,))[:M]
-    st.vis_capacity = capacity
-    if not st.compute_visibility:
-      st.visibility.zero_()
-    st.vis_ready = not (st.compute_visibility and st.needs_grad)    # without gradients the driver reduced it already
-    st.segments = _lib.GsrSegmentsC.from_buffer_copy(res.segments) if res.has_segments else None
-    st.segment_buffers = (out,)
-    image = V(plan.image, (H, W, 3))
-    st.image = image.detach() if st.needs_grad else None
+                           int(bool(st.needs_grad)), st.seg_pairs, st.seg_min, 0, None, None, None, 3, None)
+    out, plan, M, image = _run_frame(frame, st, dev, N, projected=False)
+    indexes = _arena_view(out, plan.indexes, (N,), torch.int64)[:M]
+    rows = st.rows
     ctx.save_for_backward(pos, ls, rot, al, sh, indexes, T, proj, cam)
     ctx.set_materialize_grads(False)       # unused outputs (gaussians2d / depth, usually) arrive as None
-    ctx.st, ctx.jac = st, (V(plan.jacobian, (N, 9))[:M] if plan.jacobian >= 0 else None)
+    ctx.st, ctx.jac = st, (_arena_view(out, plan.jacobian, (N, 9), torch.float32)[:M] if plan.jacobian >= 0 else None)
     ctx.grad_out, ctx.sh_out = grad_out, sh_out
     ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype, feature.dtype)
     ctx.mark_non_differentiable(indexes)
@@ -815,7 +685,8 @@ def _init_state(st: _RasterState, camera_params: CameraParams, config: RasterCon
   st.vis_partial = st.pair_vis = st.segments = st.segment_buffers = st.rows = st.image = None
   st.vis_ready, st.vis_capacity = True, 0
   st.seg_pairs, st.seg_min = int(config.segment_pairs), int(config.segment_min_pairs)
-  st.key_range = _depth_key_range(float(camera_params.near_plane), float(camera_params.far_plane))
+  st.near_far = (float(camera_params.near_plane), float(camera_params.far_plane))
+  st.key_range = _depth_key_range(*st.near_far)
 
 
 def _rendering_of(st: _RasterState, image, indexes, gaussians2d, depth, camera_params) -> Rendering:

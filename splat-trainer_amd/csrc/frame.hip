@@ -26,7 +26,7 @@ struct Cursor {
   int64_t at = 0;
   int64_t take(int64_t bytes) {
     const int64_t o = at;
-    at = align_up(at + (bytes > 0 ? bytes : 0));
+    at = align_up(at + (bytes > 0 ? bytes : 1));     // an empty buffer still gets a range of its own
     return o;
   }
 };
@@ -117,7 +117,7 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
   p->sort_ws_bytes = (int64_t)gsr_sort_workspace_bytes(N);
   p->scan_ws_bytes = (int64_t)gsr_scan_workspace_bytes(N);
   p->tsort_ws_bytes = (int64_t)gsr_sort_workspace_bytes(cap);
-  p->cull_ws = work.take(p->cull_ws_bytes);
+  p->cull_ws = projected ? -1 : work.take(p->cull_ws_bytes);
   p->sort_ws = work.take(p->sort_ws_bytes);
   p->scan_ws = work.take(p->scan_ws_bytes);
   p->tsort_ws = work.take(p->tsort_ws_bytes);

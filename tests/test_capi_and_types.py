@@ -42,6 +42,49 @@ def test_host_only_entry_points(built_libs):
   assert C.sizeof(_lib.GsrRasterParamsC) == 32
 
 
+def test_frame_plan_lays_out_disjoint_aligned_buffers(built_libs):
+  """gsr_frame_plan (host only): every buffer of a frame gets its own 256-byte aligned range inside the arena it belongs
+  to, the zero-filled head of the output arena covers exactly the buffers that must start at zero, optional buffers
+  are absent (-1) when not asked for, sizes follow N / the pair capacity / the image, in both modes of the driver."""
+  lib = _lib.load()
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+
+  def plan(N, W, H, cap, K=16, jac=1, median=0, vis=1, grad=1, projected=False, C_=3):
+    f = _lib.GsrFrameC(None if projected else 1, 1, 1, 1, 1, N, K, W, H, 1, 1, 1, 0.1, 100.0, _lib.raster_params(cfg), jac,
+                       median, vis, grad, -1, 0, cap, 1 if projected else None, 1 if projected else None,
+                       1 if projected else None, C_, None)
+    p = _lib.GsrFramePlanC()
+    rc = lib.gsr_frame_plan(C.byref(f), C.byref(p))
+    return rc, p
+
+  out_fields = ("prune_cost", "split_score", "counts", "tile_range", "vis_partial", "indexes", "rows", "screen_scale",
+                "jacobian", "visibility", "image", "final_T", "last", "median", "count", "offsets", "vals_a", "vals_b",
+                "tvals_a", "tvals_b", "trank_a", "trank_b", "pair_vis", "seg_tables", "seg_pix", "seg_last")
+  work_fields = ("cull_ws", "sort_ws", "scan_ws", "tsort_ws", "keys_a", "keys_b", "tile_hits", "tkeys_a", "tkeys_b")
+  for kw in (dict(N=500_000, W=1920, H=1080, cap=2_000_000), dict(N=10_000, W=256, H=256, cap=65_536, K=1, median=1),
+             dict(N=3_000_000, W=1920, H=1080, cap=8_000_000, grad=0), dict(N=777, W=33, H=17, cap=4096, projected=True, C_=1),
+             dict(N=1, W=1, H=1, cap=0)):
+    rc, p = plan(**kw)
+    assert rc == 0, kw
+    N, cap, P = kw["N"], kw["cap"], kw["W"] * kw["H"]
+    for fields, total in ((out_fields, p.out_bytes), (work_fields, p.work_bytes)):
+      offs = sorted(getattr(p, f) for f in fields if getattr(p, f) >= 0)
+      assert all(o % 256 == 0 for o in offs) and len(set(offs)) == len(offs) and (not offs or offs[-1] <= total), kw
+    assert p.zero_begin == 0 and p.prune_cost == 0 and p.zero_bytes % 256 == 0
+    zeroed = {f for f in out_fields if 0 <= getattr(p, f) < p.zero_bytes}
+    want_zero = {"prune_cost", "split_score", "counts", "tile_range"} | ({"vis_partial"} if (kw.get("vis", 1) or kw.get("grad", 1)) else set())
+    assert zeroed == want_zero, (kw, zeroed)
+    assert p.rows - p.indexes >= 8 * N if p.indexes >= 0 else kw.get("projected")
+    assert (p.median >= 0) == bool(kw.get("median", 0))
+    assert (p.jacobian >= 0) == (not kw.get("projected") and kw.get("K", 16) > 1)
+    assert p.final_T - p.image >= 4 * kw.get("C_", 3) * P
+    assert p.out_bytes >= 64 * N + 20 * P + 24 * cap and p.work_bytes >= 24 * N + 8 * cap
+    assert (p.seg_capacity > 0) == (cap > 0) and p.seg_heavy_capacity <= p.seg_capacity
+  assert plan(N=10, W=8, H=8, cap=16, K=5)[0] < 0                       # unsupported SH size
+  assert plan(N=10, W=8, H=8, cap=16, projected=True, C_=4)[0] < 0      # more than 3 feature channels
+  assert plan(N=-1, W=8, H=8, cap=16)[0] < 0
+
+
 def test_segment_rule_and_capacity_bounds(built_libs):
   """Host side of the list segmentation (no GPU needed): the per-frame thresholds, and the buffer bounds -- the bound
   for "at most O pairs" (what the renderer sizes its tables with before the pair count is known) must cover the exact

@@ -37,7 +37,8 @@ extern "C" {
 #define GSR_ERR_LAUNCH_FAILED -3
 #define GSR_ERR_UNSUPPORTED -4
 
-#define GSR_ROW_FLOATS 16      /* packed per-splat row, 64 bytes, splat order:  u v A B | C op depth f0 | f1 f2 0 0 | 0 0 0 0;
+#define GSR_ROW_FLOATS 16      /* packed per-splat row, 64 bytes, splat order:  u v A B | C op qlim f0 | f1 f2 depth 0 | 0 0 0 0
+                                  (qlim = min(q_max, 2 ln(op / alpha_threshold)): a pixel contributes iff q <= qlim);
                                   the gradient rows use the same pitch:  mx my mxx mxy | myy dop prune split | df0 df1 df2 vis | 0 0 0 0 */
 #define GSR_PARTIAL_FLOATS 12  /* per-(tile,splat) gradient partial: mx my mxx mxy | myy dop prune split | df0 df1 df2 -
                                   (m* = moments of G dL/dG about the splat's mean; the per-splat sweep turns their sums into
@@ -74,7 +75,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 21) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 22) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -161,7 +162,7 @@ int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, c
                           void* stream);
 
 /* ---- K2 + K3 fused  (render_gaussians: project_to_image + evaluate_sh_at in one sweep) ------------------------ */
-/* One [M,16] row per visible splat (GSR_ROW_FLOATS), written whole:  u v A B | C opacity depth f0 | f1 f2 0 0 | 0 0 0 0,
+/* One [M,16] row per visible splat (GSR_ROW_FLOATS), written whole:  u v A B | C opacity qlim f0 | f1 f2 depth 0 | 0 0 0 0,
  * exactly the values gsr_project_forward + gsr_sh_forward return (same device code).  screen_scale_out [M,2];
  * jacobian_out [M,9] or NULL, depth_keys_out [M] or NULL, count_dev or NULL as in the two single calls. */
 int gsr_project_sh_forward(const float* position, const float* log_scaling, const float* rotation_xyzw,
@@ -200,7 +201,7 @@ int gsr_depth_keys(const float* depth, int64_t M, uint32_t bias, uint32_t max_ke
  * (sigma_major, sigma_minor) in pixels, sqrt of the eigenvalues of the blurred 2D covariance.  The one-call form gets
  * the same rows straight from gsr_project_sh_forward. */
 int gsr_pack_rows(const float* gaussians2d, const float* depth, const float* features, int64_t M, int32_t C,
-                  float* rows_out, float* screen_scale_out, void* stream);
+                  const GsrRasterParamsC* params_host, float* rows_out, float* screen_scale_out, void* stream);
 /* For rank k in depth order (order[k] = splat id): gathers the splat's row -- the one crossing of the depth-order
  * permutation on the forward side, one 64-byte line per splat -- and writes the number of tiles its support touches (a
  * tile counts when the support reaches the pixel centres of its upper or lower half) and tile_hits_out [M,4] uint32:

@@ -93,27 +93,27 @@ __device__ __forceinline__ v2f clamp_alpha2(v2f a, float cmax) {
 }
 
 struct Splat {            // one splat's packed row, wave-uniform (lives in SGPRs)
-  float u, v, A, B, C, op, depth, f0, f1, f2;
+  float u, v, A, B, C, op, qlim, f0, f1, f2, depth;   // qlim = min(q_max, 2 ln(op / alpha_threshold)): q <= qlim <=> the pixel contributes
   uint32_t halves;        // bit h set: the splat's support reaches tile half h (from K4 emit)
 };
 
 // packed (splat id | half mask << 30) is wave-uniform: the three 16-byte loads from the splat's packed 64-byte row
 // (geometry.hip: project_sh_fwd_kernel / pack_rows_kernel) become scalar-cache loads.
-template <int C>
+template <int C, bool DEPTH = false>
 __device__ __forceinline__ Splat load_splat_packed(const float* __restrict__ rec, uint32_t packed) {
   const uint32_t k = packed & 0x3FFFFFFFu;
   const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_ROW_FLOATS * k);
   const float4 r0 = r[0], r1 = r[1];
   Splat s;
-  s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.depth = r1.z; s.f0 = r1.w;
-  s.f1 = 0.f; s.f2 = 0.f;
+  s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.qlim = r1.z; s.f0 = r1.w;
+  s.f1 = 0.f; s.f2 = 0.f; s.depth = 0.f;
   s.halves = packed >> 30;
-  if (C > 1) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; }
+  if (C > 1 || DEPTH) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; s.depth = r2.z; }
   return s;
 }
 
 // i is wave-uniform: the index load and the three 16-byte record loads become scalar-cache loads.
-template <int C>
+template <int C, bool DEPTH = false>
 __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const uint32_t* __restrict__ sorted_rank,
                                             uint32_t i) {
   const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)sorted_rank[i]);
@@ -121,10 +121,10 @@ __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const
   const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_ROW_FLOATS * k);
   const float4 r0 = r[0], r1 = r[1];
   Splat s;
-  s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.depth = r1.z; s.f0 = r1.w;
-  s.f1 = 0.f; s.f2 = 0.f;
+  s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.qlim = r1.z; s.f0 = r1.w;
+  s.f1 = 0.f; s.f2 = 0.f; s.depth = 0.f;
   s.halves = packed >> 30;
-  if (C > 1) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; }
+  if (C > 1 || DEPTH) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; s.depth = r2.z; }
   return s;
 }
 
@@ -195,7 +195,7 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
   // lane 16r+15 ends up with the visibility total of pair (i + {0,2,1,3}[r]) of each group of four
   const uint32_t vis_slot = (uint32_t)(((lane >> 4) & 1) * 2 + (lane >> 5));
   if (begin >= end) return;
-  Splat nxt = load_splat<C>(rec, sorted_rank, begin);
+  Splat nxt = load_splat<C, MEDIAN>(rec, sorted_rank, begin);
   for (uint32_t i = begin; i < end; i += 4) {
     if (PF && ((i - tile_start) & (GSR_K6_PREFETCH - 1)) == 0u) fwd_prefetch_step<C>(px, rec, sorted_rank, i, pf_end, lane);
     float wq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -203,7 +203,7 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
     for (int m = 0; m < 4; ++m) {
       if (i + m < end) {                                               // wave-uniform
         const Splat s = nxt;
-        if (i + m + 1 < end) nxt = load_splat<C>(rec, sorted_rank, i + m + 1);   // prefetch (scalar loads)
+        if (i + m + 1 < end) nxt = load_splat<C, MEDIAN>(rec, sorted_rank, i + m + 1);   // prefetch (scalar loads)
         const float dxa = fx0 - s.u, dya = fy0 - s.v;
         const v2f dx2 = {dxa, dxa + 8.f};
         const int idx = (int)(i - tile_start) + m + 1;
@@ -213,14 +213,14 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
           if (!(s.halves & (1u << h))) continue;                        // scalar test: support misses this half
           const float dy = h ? dya + 8.f : dya;
           const v2f q = eval_q2(dx2, dy, s.A, s.B, s.C);
-          const bool in0 = px.T2[h].x >= rp.T_eps && q.x <= rp.q_max;
-          const bool in1 = px.T2[h].y >= rp.T_eps && q.y <= rp.q_max;
-          if (__ballot(in0 || in1) != 0ull) {
+          // q <= qlim = min(q_max, 2 ln(opacity / alpha_threshold)) says both "inside the support" and "alpha reaches
+          // the threshold" (alpha = opacity exp(-q/2); the clamp at 0.99 lies above the threshold)
+          const bool hit0 = px.T2[h].x >= rp.T_eps && q.x <= s.qlim;
+          const bool hit1 = px.T2[h].y >= rp.T_eps && q.y <= s.qlim;
+          if (__ballot(hit0 || hit1) != 0ull) {
             const v2f G = eval_G2(q);
             const v2f a_raw = G * s.op;
             v2f alpha = clamp_alpha2(a_raw, rp.clamp_max_alpha);
-            const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
-            const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
             alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
             const v2f w = alpha * px.T2[h];
             px.col2[h][0] = __builtin_elementwise_fma(w, GSR_V2(s.f0), px.col2[h][0]);
@@ -293,11 +293,10 @@ __device__ __forceinline__ void seg_alpha_pass(uint32_t sidx, const float* __res
       if (!(s.halves & (1u << h))) continue;
       const float dy = h ? dya + 8.f : dya;
       const v2f q = eval_q2(dx2, dy, s.A, s.B, s.C);
-      const bool in0 = q.x <= rp.q_max, in1 = q.y <= rp.q_max;
+      const bool in0 = q.x <= s.qlim, in1 = q.y <= s.qlim;
       if (__ballot(in0 || in1) != 0ull) {
         v2f alpha = clamp_alpha2(eval_G2(q) * s.op, rp.clamp_max_alpha);
-        alpha = (v2f){(in0 && alpha.x >= rp.alpha_threshold) ? alpha.x : 0.f,
-                      (in1 && alpha.y >= rp.alpha_threshold) ? alpha.y : 0.f};
+        alpha = (v2f){in0 ? alpha.x : 0.f, in1 ? alpha.y : 0.f};
         P2[h] = P2[h] - alpha * P2[h];
       }
     }
@@ -619,14 +618,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
         const float dy = h ? dya + 8.f : dya;
         v2f q, tx_, ty_;
         eval_qt(dx2, dy, s.A, s.B, s.C, q, tx_, ty_);
-        const bool in0 = pos < lastc[2 * h] && q.x <= rp.q_max;
-        const bool in1 = pos < lastc[2 * h + 1] && q.y <= rp.q_max;
-        if (__ballot(in0 || in1) != 0ull) {
+        const bool hit0 = pos < lastc[2 * h] && q.x <= s.qlim;       // the forward walk's test (see fwd_walk)
+        const bool hit1 = pos < lastc[2 * h + 1] && q.y <= s.qlim;
+        if (__ballot(hit0 || hit1) != 0ull) {
           const v2f G = eval_G2(q);
           const v2f a_raw = G * s.op;
           v2f alpha = clamp_alpha2(a_raw, rp.clamp_max_alpha);
-          const bool hit0 = in0 && alpha.x >= rp.alpha_threshold;
-          const bool hit1 = in1 && alpha.y >= rp.alpha_threshold;
           alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
           const v2f om = GSR_V2(1.f) - alpha;
           const v2f inv = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};   // rcp(1) == 1 exactly

@@ -163,7 +163,8 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
   GSR_TRY(gsr_depth_key_range(f->near_plane, f->far_plane, &key_bias, &key_max));
   uint32_t* keys_a = at<uint32_t>(work, p->keys_a);
   if (projected) {
-    GSR_TRY(gsr_pack_rows(f->gaussians2d, f->depth, f->features, N, f->C, rows, at<float>(out, p->screen_scale), stream_));
+    GSR_TRY(gsr_pack_rows(f->gaussians2d, f->depth, f->features, N, f->C, &f->params, rows,
+                          at<float>(out, p->screen_scale), stream_));
     if (!f->depth_order) GSR_TRY(gsr_depth_keys(f->depth, N, key_bias, key_max, keys_a, stream_));
   } else {
     int64_t* indexes = at<int64_t>(out, p->indexes);

@@ -200,6 +200,13 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(const float* __restrict__ s
   }
 }
 
+// q <= qlim  <=>  the pixel is inside the support (q <= q_max) AND alpha = opacity exp(-q/2) reaches the threshold:
+// the composite kernels test ONE per-splat number per pixel instead of q and alpha separately.  One definition for every
+// kernel that writes rows (same bits for the same opacity).  opacity below the threshold: negative (no pixel passes).
+__device__ __forceinline__ float gsr_qlim(float opacity, const GsrRasterParams& rp) {
+  return fminf(rp.q_max, 2.f * logf(opacity / rp.alpha_threshold));
+}
+
 // sigma = sqrt(eig(cov)) of a projected splat from its conic: cov = conic^-1 = [C -B; -B A] / det(conic).
 // One definition (rounding pinned) for every kernel that reports points.screen_scale.
 __device__ __forceinline__ float2 gsr_screen_scale(float A, float B, float C) {
@@ -211,7 +218,7 @@ __device__ __forceinline__ float2 gsr_screen_scale(float A, float B, float C) {
 }
 
 // K2 + K3 fused: ONE 64-byte row per visible splat, written whole (four 16-byte stores by one thread = one full
-// line), in splat order:   u v A B | C opacity depth f0 | f1 f2 0 0 | 0 0 0 0.
+// line), in splat order:   u v A B | C opacity qlim f0 | f1 f2 depth 0 | 0 0 0 0.
 // Everything downstream of the projection -- K4's gather through the depth order, the scalar record loads of K6 / K7 --
 // reads this row and nothing else, so the depth-order permutation costs one line per splat instead of one per source
 // array.  Also written: screen_scale (M,2), the depth sort's keys, and (JAC) d colour / d position for the backward pass.
@@ -300,8 +307,9 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
   float* s_jac = s_rows + 256 * OP;
   if (valid) {
     float* d = s_out + tid * OP;
-    d[0] = o.u; d[1] = o.v; d[2] = o.A; d[3] = o.B; d[4] = o.C; d[5] = o.opacity; d[6] = o.depth; d[7] = col[0];
-    d[8] = col[1]; d[9] = col[2]; d[10] = 0.f; d[11] = 0.f; d[12] = 0.f; d[13] = 0.f; d[14] = 0.f; d[15] = 0.f;
+    d[0] = o.u; d[1] = o.v; d[2] = o.A; d[3] = o.B; d[4] = o.C; d[5] = o.opacity; d[6] = gsr_qlim(o.opacity, rp);
+    d[7] = col[0]; d[8] = col[1]; d[9] = col[2]; d[10] = o.depth; d[11] = 0.f; d[12] = 0.f; d[13] = 0.f; d[14] = 0.f;
+    d[15] = 0.f;
     if (JAC) {
 #pragma unroll
       for (int e = 0; e < 9; ++e) s_jac[tid * 9 + e] = J[e];
@@ -328,8 +336,8 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
   if (!valid) return;
   float4* r = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
   r[0] = make_float4(o.u, o.v, o.A, o.B);
-  r[1] = make_float4(o.C, o.opacity, o.depth, col[0]);
-  r[2] = make_float4(col[1], col[2], 0.f, 0.f);
+  r[1] = make_float4(o.C, o.opacity, gsr_qlim(o.opacity, rp), col[0]);
+  r[2] = make_float4(col[1], col[2], o.depth, 0.f);
   r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(o.A, o.B, o.C);
   if (depth_keys) depth_keys[m] = gsr_depth_key(o.depth, key_bias, key_max);
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
 // caller: the reference's colour MLP sits between the projection and the rasterizer, mlp_scene.py:415-419).
 template <int C>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ g2d, const float* __restrict__ depth,
-                                                        const float* __restrict__ feat, int64_t M,
+                                                        const float* __restrict__ feat, int64_t M, GsrRasterParams rp,
                                                         float* __restrict__ rows, float* __restrict__ sscale) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
@@ -355,8 +363,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
   const float f0 = feat[C * m], f1 = C > 1 ? feat[C * m + 1] : 0.f, f2 = C > 2 ? feat[C * m + 2] : 0.f;
   float4* r = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
   r[0] = make_float4(uv.x, uv.y, ab.x, ab.y);
-  r[1] = make_float4(co.x, co.y, depth[m], f0);
-  r[2] = make_float4(f1, f2, 0.f, 0.f);
+  r[1] = make_float4(co.x, co.y, gsr_qlim(co.y, rp), f0);
+  r[2] = make_float4(f1, f2, depth[m], 0.f);
   r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(ab.x, ab.y, co.x);
 }
@@ -658,7 +666,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 21; }
+int gsr_abi_version(void) { return 22; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -779,16 +787,17 @@ int gsr_project_sh_forward(const float* position, const float* log_scaling, cons
 }
 
 int gsr_pack_rows(const float* gaussians2d, const float* depth, const float* features, int64_t M, int32_t C,
-                  float* rows_out, float* screen_scale_out, void* stream_) {
+                  const GsrRasterParamsC* params_host, float* rows_out, float* screen_scale_out, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M < 0 || !params_host) return GSR_ERR_INVALID_ARGUMENT;
+  const GsrRasterParams rp = to_params(params_host);
   if (C < 1 || C > 3) return GSR_ERR_UNSUPPORTED;
   if (M == 0) return GSR_OK;
   if (!gaussians2d || !depth || !features || !rows_out || !screen_scale_out) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(M, 256);
-  if (C == 1) pack_rows_kernel<1><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rows_out, screen_scale_out);
-  else if (C == 2) pack_rows_kernel<2><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rows_out, screen_scale_out);
-  else pack_rows_kernel<3><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rows_out, screen_scale_out);
+  if (C == 1) pack_rows_kernel<1><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rp, rows_out, screen_scale_out);
+  else if (C == 2) pack_rows_kernel<2><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rp, rows_out, screen_scale_out);
+  else pack_rows_kernel<3><<<g, 256, 0, stream>>>(gaussians2d, depth, features, M, rp, rows_out, screen_scale_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

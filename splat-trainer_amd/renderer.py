@@ -560,7 +560,7 @@ class _FrameFn(torch.autograd.Function):
       ctx.st, ctx.jac, ctx.grad_out, ctx.sh_out = st, None, grad_out, sh_out
       ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype, feature.dtype)
       ctx.mark_non_differentiable(indexes)
-      return image, rows[:, 0:6], rows[:, 6:7], indexes
+      return image, rows[:, 0:6], rows[:, 10:11], indexes
     frame = _lib.GsrFrameC(pos.data_ptr(), ls.data_ptr(), rot.data_ptr(), al.data_ptr(), sh.data_ptr(), N, K, W, H,
                            T.data_ptr(), proj.data_ptr(), cam.data_ptr(), near, far, st.params,
                            int(bool(want_pos_grad and K > 1)), int(st.want_median), int(st.compute_visibility),
@@ -574,7 +574,7 @@ class _FrameFn(torch.autograd.Function):
     ctx.grad_out, ctx.sh_out = grad_out, sh_out
     ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype, feature.dtype)
     ctx.mark_non_differentiable(indexes)
-    return image, rows[:, 0:6], rows[:, 6:7], indexes
+    return image, rows[:, 0:6], rows[:, 10:11], indexes
 
   @staticmethod
   def backward(ctx, d_image, d_g2d, d_depth, _d_indexes):

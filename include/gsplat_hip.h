@@ -75,7 +75,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 22) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 23) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -160,6 +160,13 @@ int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, c
                           int64_t camera_stride, int32_t num_cameras, const float* sh_features, const float* positions,
                           int64_t N, int32_t K, float* d_sh_features, float* d_positions, int32_t accumulate,
                           void* stream);
+
+/* The depth sort's keys of the visible splats from their positions alone (what gsr_project_forward /
+ * gsr_project_sh_forward write as depth_keys_out, bit for bit): lets a caller start the depth sort right behind the cull,
+ * on a second stream, while the projection / colour sweep runs on the first (the frame driver does). */
+int gsr_depth_keys_from_positions(const float* position, const int64_t* indexes, int64_t M, const uint32_t* count_dev,
+                                  const float* T_camera_world, const float* projection, uint32_t depth_key_bias,
+                                  uint32_t depth_key_max, uint32_t* keys_out, void* stream);
 
 /* ---- K2 + K3 fused  (render_gaussians: project_to_image + evaluate_sh_at in one sweep) ------------------------ */
 /* One [M,16] row per visible splat (GSR_ROW_FLOATS), written whole:  u v A B | C opacity qlim f0 | f1 f2 depth 0 | 0 0 0 0,
@@ -325,6 +332,12 @@ typedef struct GsrFrameC {
   const float* features;        /* [N,C] */
   int32_t C;                    /* 1..3 (3 in the one-call form) */
   const uint32_t* depth_order;  /* [N] or NULL: the depth order when the caller has it already (skips the depth sort) */
+  /* One-call form only, all three or none: a second stream on which the depth sort (keys from the positions) runs
+   * while the projection / colour sweep occupies `stream`; event_fork is recorded on `stream` behind the cull,
+   * event_join on side_stream behind the sort (hipEvent_t, caller-owned, timing disabled). */
+  void* side_stream;
+  void* event_fork;
+  void* event_join;
 } GsrFrameC;
 /* Byte offsets of the frame's buffers inside the two caller-owned arenas (-1: not present in this frame).  `out`:
  * everything the Rendering or the backward pass still needs after the forward pass; the first zero_bytes bytes are

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -38,7 +38,8 @@ class GsrFrameC(C.Structure):
               ("params", GsrRasterParamsC), ("want_jacobian", C.c_int32), ("want_median", C.c_int32),
               ("compute_visibility", C.c_int32), ("needs_grad", C.c_int32), ("seg_pairs", C.c_int32),
               ("seg_min_pairs", C.c_int32), ("pair_capacity", C.c_int64), ("gaussians2d", C.c_void_p),
-              ("depth", C.c_void_p), ("features", C.c_void_p), ("C", C.c_int32), ("depth_order", C.c_void_p)]
+              ("depth", C.c_void_p), ("features", C.c_void_p), ("C", C.c_int32), ("depth_order", C.c_void_p),
+              ("side_stream", C.c_void_p), ("event_fork", C.c_void_p), ("event_join", C.c_void_p)]
 
 
 FRAME_PLAN_FIELDS = ("out_bytes", "work_bytes", "zero_begin", "zero_bytes", "prune_cost", "split_score", "counts",
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "gsr_sh_backward_dense": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     "gsr_depth_key_range": (C.c_int, [_f, _f, _p, _p]),
     "gsr_depth_keys": (C.c_int, [_p, _i64, _u32, _u32, _p, _p]),
+    "gsr_depth_keys_from_positions": (C.c_int, [_p, _p, _i64, _p, _p, _p, _u32, _u32, _p, _p]),
     "gsr_project_sh_forward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _pp, _p, _p, _p, _p, _p, _u32,
                                          _u32, _p]),
     "gsr_project_backward_rows": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _pp, _p, _p, _p, _p, _p, _p, _p,

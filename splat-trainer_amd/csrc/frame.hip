@@ -150,6 +150,7 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
   uint32_t* M_dev = projected ? nullptr : counts;          // projected mode: N is exact
   uint32_t* O_dev = counts + 1;
   int rc;
+  bool forked = false;
 #define GSR_TRY(call)          \
   do {                         \
     rc = (call);               \
@@ -171,10 +172,21 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
     GSR_TRY(gsr_frustum_cull(f->position, N, f->T_camera_world, f->projection, f->W, f->H, f->near_plane, f->far_plane,
                              f->params.margin_px, indexes, M_dev, at<uint8_t>(work, p->cull_ws),
                              (size_t)p->cull_ws_bytes, stream_));
+    forked = f->side_stream && f->event_fork && f->event_join;
+    if (forked) {
+      // the depth sort -- nine small latency-bound launches -- goes to the side stream with keys formed from the
+      // positions alone, and runs while the fused K2 + K3 sweep streams the coefficient rows on this one
+      hipStream_t side = reinterpret_cast<hipStream_t>(f->side_stream);
+      if (hipEventRecord(reinterpret_cast<hipEvent_t>(f->event_fork), stream) != hipSuccess ||
+          hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(f->event_fork), 0) != hipSuccess)
+        return GSR_ERR_LAUNCH_FAILED;
+      GSR_TRY(gsr_depth_keys_from_positions(f->position, indexes, N, M_dev, f->T_camera_world, f->projection, key_bias,
+                                            key_max, keys_a, f->side_stream));
+    }
     GSR_TRY(gsr_project_sh_forward(f->position, f->log_scaling, f->rotation_xyzw, f->alpha_logit, f->sh_features, f->K,
                                    indexes, N, f->T_camera_world, f->projection, f->camera_pos, &f->params, rows,
-                                   at<float>(out, p->screen_scale), at<float>(out, p->jacobian), M_dev, keys_a, key_bias,
-                                   key_max, stream_));
+                                   at<float>(out, p->screen_scale), at<float>(out, p->jacobian), M_dev,
+                                   forked ? nullptr : keys_a, key_bias, key_max, stream_));
   }
   // depth order of the visible splats (stable: ties keep ascending index), keys written by the projection
   uint32_t* vals_a = at<uint32_t>(out, p->vals_a);
@@ -183,9 +195,13 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
   res->order = -1;                                          // the caller's own array
   if (!order) {
     GSR_TRY(gsr_sort_pairs_u32(keys_a, vals_a, at<uint32_t>(work, p->keys_b), vals_b, N, 1, 0, bit_length(key_max),
-                               at<uint8_t>(work, p->sort_ws), (size_t)p->sort_ws_bytes, M_dev, stream_));
+                               at<uint8_t>(work, p->sort_ws), (size_t)p->sort_ws_bytes, M_dev,
+                               forked ? f->side_stream : stream_));
     res->order = rc == 1 ? p->vals_b : p->vals_a;
     order = rc == 1 ? vals_b : vals_a;
+    if (forked && (hipEventRecord(reinterpret_cast<hipEvent_t>(f->event_join), reinterpret_cast<hipStream_t>(f->side_stream)) != hipSuccess ||
+                   hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(f->event_join), 0) != hipSuccess))
+      return GSR_ERR_LAUNCH_FAILED;
   }
   uint32_t* count = at<uint32_t>(out, p->count);
   uint32_t* offsets = at<uint32_t>(out, p->offsets);

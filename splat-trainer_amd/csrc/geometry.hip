@@ -82,6 +82,23 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(const float* __restric
   if (depth_keys) depth_keys[m] = gsr_depth_key(o.depth, key_bias, key_max);
 }
 
+// The depth sort's keys straight from the positions (12 bytes per visible splat): lets the sort start right behind the cull,
+// on a second stream, while the fused K2 + K3 kernel streams the coefficient rows on the first.  Same depth bits as the
+// projection writes into the rows (gsr_to_camera: formed in double, rounded once).
+__global__ __launch_bounds__(256) void depth_keys_pos_kernel(const float* __restrict__ pos, const int64_t* __restrict__ idx,
+                                                             int64_t M, const uint32_t* __restrict__ count_dev,
+                                                             const float* __restrict__ Tcw, const float* __restrict__ proj,
+                                                             uint32_t* __restrict__ keys, uint32_t key_bias,
+                                                             uint32_t key_max) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M || (count_dev != nullptr && m >= (int64_t)*count_dev)) return;
+  const GsrCam cam = gsr_load_cam(Tcw, proj);
+  const int64_t i = idx[m];
+  float x, y, z;
+  gsr_to_camera(cam, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], x, y, z);
+  keys[m] = gsr_depth_key(z, key_bias, key_max);
+}
+
 template <bool ACC>
 __global__ __launch_bounds__(256) void project_bwd_kernel(const float* __restrict__ pos, const float* __restrict__ ls,
                                                           const float* __restrict__ rot, const float* __restrict__ logit,
@@ -666,7 +683,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 22; }
+int gsr_abi_version(void) { return 23; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -750,6 +767,19 @@ int gsr_project_backward(const float* position, const float* log_scaling, const 
                                                                    indexes, M, T_camera_world, projection,
                                                                    to_params(params_host), dL_dgaussians2d, dL_ddepth,
                                                                    d_position, d_log_scaling, d_rotation, d_alpha_logit);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_depth_keys_from_positions(const float* position, const int64_t* indexes, int64_t M, const uint32_t* count_dev,
+                                  const float* T_camera_world, const float* projection, uint32_t depth_key_bias,
+                                  uint32_t depth_key_max, uint32_t* keys_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) return GSR_OK;
+  if (!position || !indexes || !T_camera_world || !projection || !keys_out) return GSR_ERR_INVALID_ARGUMENT;
+  depth_keys_pos_kernel<<<grid_for(M, 256), 256, 0, stream>>>(position, indexes, M, count_dev, T_camera_world, projection,
+                                                             keys_out, depth_key_bias, depth_key_max);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -145,6 +145,27 @@ def _readback_slot(device):
   return pool[key]
 
 
+# GSPLAT_HIP_SIDE_STREAM=1: the frame driver puts the depth sort on a second stream next to the fused K2 + K3 sweep.
+# Measured (same box, median ms/step, off -> on): c1 0.511 -> 0.583, c2 0.958 -> 0.979, c3 2.705 -> 2.682: the cross-stream
+# hand-off costs more than the nine small sort launches hide except at millions of splats; off by default.
+SIDE_STREAM = os.environ.get("GSPLAT_HIP_SIDE_STREAM", "0") == "1"
+
+
+def _side_stream(device):
+  """(stream, fork event, join event) of this thread for ``device``: the frame driver puts the depth sort on the side
+  stream while the fused projection + colour sweep runs on the current one (csrc/frame.hip).  Created once; the events
+  have been recorded once so that their native handles exist."""
+  pool = _TLS.__dict__.setdefault("side", {})
+  key = device.index
+  if key not in pool:
+    stream = torch.cuda.Stream(device=device)
+    fork, join = torch.cuda.Event(), torch.cuda.Event()
+    fork.record(_lib.current_stream())
+    join.record(_lib.current_stream())
+    pool[key] = (stream, fork, join)
+  return pool[key]
+
+
 def _start_readback(words: torch.Tensor):
   """Begins the device->host copy of a few int32 words on the current stream and returns ``wait() -> list``.
   The two sizes the path cannot know in advance (visible splats, tile overlaps) come back this way: whatever is
@@ -565,6 +586,9 @@ class _FrameFn(torch.autograd.Function):
                            T.data_ptr(), proj.data_ptr(), cam.data_ptr(), near, far, st.params,
                            int(bool(want_pos_grad and K > 1)), int(st.want_median), int(st.compute_visibility),
                            int(bool(st.needs_grad)), st.seg_pairs, st.seg_min, 0, None, None, None, 3, None)
+    if SIDE_STREAM:
+      side, fork, join = _side_stream(dev)
+      frame.side_stream, frame.event_fork, frame.event_join = side.cuda_stream, fork.cuda_event, join.cuda_event
     out, plan, M, image = _run_frame(frame, st, dev, N, projected=False)
     indexes = _arena_view(out, plan.indexes, (N,), torch.int64)[:M]
     rows = st.rows

@@ -52,7 +52,7 @@ def test_frame_plan_lays_out_disjoint_aligned_buffers(built_libs):
   def plan(N, W, H, cap, K=16, jac=1, median=0, vis=1, grad=1, projected=False, C_=3):
     f = _lib.GsrFrameC(None if projected else 1, 1, 1, 1, 1, N, K, W, H, 1, 1, 1, 0.1, 100.0, _lib.raster_params(cfg), jac,
                        median, vis, grad, -1, 0, cap, 1 if projected else None, 1 if projected else None,
-                       1 if projected else None, C_, None)
+                       1 if projected else None, C_, None, None, None, None)
     p = _lib.GsrFramePlanC()
     rc = lib.gsr_frame_plan(C.byref(f), C.byref(p))
     return rc, p

@@ -37,12 +37,13 @@ extern "C" {
 #define GSR_ERR_LAUNCH_FAILED -3
 #define GSR_ERR_UNSUPPORTED -4
 
-#define GSR_ROW_FLOATS 16      /* packed per-splat row, 64 bytes, splat order:  u v A B | C op qlim f0 | f1 f2 depth 0 | 0 0 0 0
+#define GSR_ROW_FLOATS 16      /* packed per-splat row, 64 bytes, splat order:  u v A B | C op qlim f0 | f1 f2 depth log2(op) | 0 0 0 0
                                   (qlim = min(q_max, 2 ln(op / alpha_threshold)): a pixel contributes iff q <= qlim);
                                   the gradient rows use the same pitch:  mx my mxx mxy | myy dop prune split | df0 df1 df2 vis | 0 0 0 0 */
-#define GSR_PARTIAL_FLOATS 12  /* per-(tile,splat) gradient partial: mx my mxx mxy | myy dop prune split | df0 df1 df2 -
-                                  (m* = moments of G dL/dG about the splat's mean; the per-splat sweep turns their sums into
-                                  du = A mx + B my, dv = B mx + C my, dA = -mxx/2, dB = -mxy, dC = -myy/2) */
+#define GSR_PARTIAL_FLOATS 12  /* per-(tile,splat) gradient partial: mx my mxx mxy | myy m0 prune split | df0 df1 df2 -
+                                  (m* = moments of G dL/dG about the splat's mean, m0 the zeroth; the per-splat sweep turns
+                                  their sums into du = A mx + B my, dv = B mx + C my, dA = -mxx/2, dB = -mxy, dC = -myy/2,
+                                  dopacity = m0 / opacity) */
 
 #ifndef GSR_HAVE_RASTER_PARAMS
 #define GSR_HAVE_RASTER_PARAMS
@@ -75,7 +76,7 @@ typedef struct GsrSegmentsC {
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
 } GsrSegmentsC;
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 23) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 24) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restric
   float* g = dg2d + 6 * m;
   *reinterpret_cast<float2*>(g) = make_float2(cA * g0.x + cB * g0.y, cB * g0.x + cC * g0.y);
   *reinterpret_cast<float2*>(g + 2) = make_float2(-0.5f * g0.z, -g0.w);
-  *reinterpret_cast<float2*>(g + 4) = make_float2(-0.5f * g1.x, g1.y);
+  const float op = fr[1].y;
+  *reinterpret_cast<float2*>(g + 4) = make_float2(-0.5f * g1.x, op > 0.f ? g1.y / op : 0.f);
   if (prune) prune[m] = g1.z;
   if (split) split[m] = g1.w;
   if (vis) vis[m] = g2.w;

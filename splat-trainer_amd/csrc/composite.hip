@@ -80,6 +80,11 @@ __device__ __forceinline__ void eval_qt(v2f dx, float dy, float A, float B, floa
   q = eval_q2(dx, dy, A, B, C);
 #endif
 }
+__device__ __forceinline__ v2f eval_alpha2(v2f q, float l2op) {     // opacity exp(-q/2) = 2^(q * -0.5*log2(e) + log2 opacity)
+#pragma clang fp contract(off)
+  const v2f e = __builtin_elementwise_fma(q, GSR_V2(-0.72134752044448170368f), GSR_V2(l2op));
+  return (v2f){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+}
 __device__ __forceinline__ v2f eval_G2(v2f q) {     // exp(-q/2) = 2^(q * -0.5*log2(e))
 #pragma clang fp contract(off)
   const v2f e = q * -0.72134752044448170368f;
@@ -93,7 +98,7 @@ __device__ __forceinline__ v2f clamp_alpha2(v2f a, float cmax) {
 }
 
 struct Splat {            // one splat's packed row, wave-uniform (lives in SGPRs)
-  float u, v, A, B, C, op, qlim, f0, f1, f2, depth;   // qlim = min(q_max, 2 ln(op / alpha_threshold)): q <= qlim <=> the pixel contributes
+  float u, v, A, B, C, op, qlim, f0, f1, f2, depth, l2op;   // l2op = log2(opacity) (backward walk: alpha = 2^(q c + l2op))   // qlim = min(q_max, 2 ln(op / alpha_threshold)): q <= qlim <=> the pixel contributes
   uint32_t halves;        // bit h set: the splat's support reaches tile half h (from K4 emit)
 };
 
@@ -106,9 +111,9 @@ __device__ __forceinline__ Splat load_splat_packed(const float* __restrict__ rec
   const float4 r0 = r[0], r1 = r[1];
   Splat s;
   s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.qlim = r1.z; s.f0 = r1.w;
-  s.f1 = 0.f; s.f2 = 0.f; s.depth = 0.f;
+  s.f1 = 0.f; s.f2 = 0.f; s.depth = 0.f; s.l2op = 0.f;
   s.halves = packed >> 30;
-  if (C > 1 || DEPTH) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; s.depth = r2.z; }
+  if (C > 1 || DEPTH) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; s.depth = r2.z; s.l2op = r2.w; }
   return s;
 }
 
@@ -122,9 +127,9 @@ __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const
   const float4 r0 = r[0], r1 = r[1];
   Splat s;
   s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.op = r1.y; s.qlim = r1.z; s.f0 = r1.w;
-  s.f1 = 0.f; s.f2 = 0.f; s.depth = 0.f;
+  s.f1 = 0.f; s.f2 = 0.f; s.depth = 0.f; s.l2op = 0.f;
   s.halves = packed >> 30;
-  if (C > 1 || DEPTH) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; s.depth = r2.z; }
+  if (C > 1 || DEPTH) { const float4 r2 = r[2]; s.f1 = r2.x; s.f2 = r2.y; s.depth = r2.z; s.l2op = r2.w; }
   return s;
 }
 
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
     uint64_t flags = __ballot(pv > 0.f);
     if (flags == 0ull) continue;
     int j = 63 - __builtin_clzll(flags);
-    Splat nxt = load_splat_packed<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+    Splat nxt = load_splat_packed<C, true>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
     uint32_t inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
     while (true) {
       const Splat s = nxt;
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
       const bool more = flags != 0ull;
       if (more) {                                             // prefetch the next contributing pair
         j = 63 - __builtin_clzll(flags);
-        nxt = load_splat_packed<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+        nxt = load_splat_packed<C, true>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
         inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
       }
       const float dxa = fx0 - s.u, dya = fy0 - s.v;
@@ -609,7 +614,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
       // Per pair and pixel the geometry gradient enters through ONE scalar, GdG = G dL/dG; what is accumulated are its
       // moments about the splat's mean, sum GdG {dx, dy, dx^2, dx dy, dy^2} -- fewer packed operations per half than
       // accumulating du, dv, dA, dB, dC themselves -- and the per-splat sweep that consumes the reduced rows converts
-      // them once per splat:  du = A mx + B my, dv = B mx + C my, dA = -mxx / 2, dB = -mxy, dC = -myy / 2.
+      // them once per splat:  du = A mx + B my, dv = B mx + C my, dA = -mxx / 2, dB = -mxy, dC = -myy / 2,
+      // dopacity = m0 / opacity (m0 = sum GdG, the zeroth moment).
       v2f mx2 = GSR_V2(0.f), my2 = mx2, mxx2 = mx2, mxy2 = mx2, myy2 = mx2, dop2 = mx2, prune2 = mx2, split2 = mx2;
       v2f df2[3] = {mx2, mx2, mx2};
 #pragma unroll
@@ -621,8 +627,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
         const bool hit0 = pos < lastc[2 * h] && q.x <= s.qlim;       // the forward walk's test (see fwd_walk)
         const bool hit1 = pos < lastc[2 * h + 1] && q.y <= s.qlim;
         if (__ballot(hit0 || hit1) != 0ull) {
-          const v2f G = eval_G2(q);
-          const v2f a_raw = G * s.op;
+          // alpha = opacity exp(-q/2) in one step, 2^(q c + log2 opacity): the backward walk never needs G = exp(-q/2)
+          // by itself -- G dL/dG = alpha dL/dalpha where the clamp is inactive -- so one packed multiply per half goes
+          const v2f a_raw = eval_alpha2(q, s.l2op);
           v2f alpha = clamp_alpha2(a_raw, rp.clamp_max_alpha);
           alpha = (v2f){hit0 ? alpha.x : 0.f, hit1 ? alpha.y : 0.f};
           const v2f om = GSR_V2(1.f) - alpha;
@@ -644,10 +651,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
           // gradient through G = exp(-q/2) only where the pixel contributed and the alpha clamp is inactive
           const bool m0 = hit0 && a_raw.x <= rp.clamp_max_alpha;
           const bool m1 = hit1 && a_raw.y <= rp.clamp_max_alpha;
-          v2f GdL = G * dLda;
-          GdL = (v2f){m0 ? GdL.x : 0.f, m1 ? GdL.y : 0.f};
-          dop2 += GdL;
-          const v2f GdG = GdL * s.op;                        // G * dL/dG
+          v2f GdG = a_raw * dLda;                            // G dL/dG = alpha dL/dalpha (clamp inactive)
+          GdG = (v2f){m0 ? GdG.x : 0.f, m1 ? GdG.y : 0.f};
+          dop2 += GdG;                                       // zeroth moment: dL/dopacity = (sum GdG) / opacity, formed per splat
           const v2f px_ = GdG * dx2, py_ = GdG * dy;
           mx2 += px_;
           my2 += py_;

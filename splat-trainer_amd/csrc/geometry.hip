@@ -235,7 +235,7 @@ __device__ __forceinline__ float2 gsr_screen_scale(float A, float B, float C) {
 }
 
 // K2 + K3 fused: ONE 64-byte row per visible splat, written whole (four 16-byte stores by one thread = one full
-// line), in splat order:   u v A B | C opacity qlim f0 | f1 f2 depth 0 | 0 0 0 0.
+// line), in splat order:   u v A B | C opacity qlim f0 | f1 f2 depth log2(opacity) | 0 0 0 0.
 // Everything downstream of the projection -- K4's gather through the depth order, the scalar record loads of K6 / K7 --
 // reads this row and nothing else, so the depth-order permutation costs one line per splat instead of one per source
 // array.  Also written: screen_scale (M,2), the depth sort's keys, and (JAC) d colour / d position for the backward pass.
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
   if (valid) {
     float* d = s_out + tid * OP;
     d[0] = o.u; d[1] = o.v; d[2] = o.A; d[3] = o.B; d[4] = o.C; d[5] = o.opacity; d[6] = gsr_qlim(o.opacity, rp);
-    d[7] = col[0]; d[8] = col[1]; d[9] = col[2]; d[10] = o.depth; d[11] = 0.f; d[12] = 0.f; d[13] = 0.f; d[14] = 0.f;
-    d[15] = 0.f;
+    d[7] = col[0]; d[8] = col[1]; d[9] = col[2]; d[10] = o.depth; d[11] = log2f(o.opacity); d[12] = 0.f; d[13] = 0.f;
+    d[14] = 0.f; d[15] = 0.f;
     if (JAC) {
 #pragma unroll
       for (int e = 0; e < 9; ++e) s_jac[tid * 9 + e] = J[e];
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
   float4* r = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
   r[0] = make_float4(o.u, o.v, o.A, o.B);
   r[1] = make_float4(o.C, o.opacity, gsr_qlim(o.opacity, rp), col[0]);
-  r[2] = make_float4(col[1], col[2], o.depth, 0.f);
+  r[2] = make_float4(col[1], col[2], o.depth, log2f(o.opacity));
   r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(o.A, o.B, o.C);
   if (depth_keys) depth_keys[m] = gsr_depth_key(o.depth, key_bias, key_max);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
   float4* r = reinterpret_cast<float4*>(rows + (int64_t)GSR_ROW_FLOATS * m);
   r[0] = make_float4(uv.x, uv.y, ab.x, ab.y);
   r[1] = make_float4(co.x, co.y, gsr_qlim(co.y, rp), f0);
-  r[2] = make_float4(f1, f2, depth[m], 0.f);
+  r[2] = make_float4(f1, f2, depth[m], log2f(co.y));
   r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(ab.x, ab.y, co.x);
 }
@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void project_bwd_rows_kernel(
   // of fetched from the row table (a 64-byte line per splat for 12 bytes: +35 us at 3M splats, measured).
   const GsrProjected fo = gsr_project_one(cam, rp, p, s, q, logit[i]);
   const float cA = fo.A, cB = fo.B, cC = fo.C;
-  float g[6] = {cA * g0.x + cB * g0.y, cB * g0.x + cC * g0.y, -0.5f * g0.z, -g0.w, -0.5f * g1.x, g1.y};
+  float g[6] = {cA * g0.x + cB * g0.y, cB * g0.x + cC * g0.y, -0.5f * g0.z, -g0.w, -0.5f * g1.x,
+                fo.opacity > 0.f ? g1.y / fo.opacity : 0.f};
   if (dg2d_extra) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) g[k] += dg2d_extra[6 * m + k];
@@ -683,7 +684,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 23; }
+int gsr_abi_version(void) { return 24; }
 
 const char* gsr_error_string(int code) {
   switch (code) {

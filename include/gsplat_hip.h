@@ -269,7 +269,9 @@ int gsr_composite_forward(const float* rows /* [M,16] */, const uint32_t* sorted
                           int32_t prefetch_rows /* speed only: touch the rows 32-64 pairs ahead of the walk (pays once the
                                                    row table has outgrown the caches: GSR_PREFETCH_MIN_ROWS) */,
                           void* stream);
+#ifndef GSR_PREFETCH_MIN_ROWS
 #define GSR_PREFETCH_MIN_ROWS 1000000
+#endif
 
 /* ---- K7 alpha-composite backward (per-pixel reverse walk) ----------------------------------------------- */
 /* partial_out [O,12]: written only for pairs with pair_vis > 0 (the others are never read). */

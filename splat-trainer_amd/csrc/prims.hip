@@ -155,16 +155,18 @@ int scan_impl(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* total_dev
 // Stable LSD radix sort, three launches per pass:
 //   rs_hist        per-block digit histogram (LDS atomics) -> hist[digit][block]
 //   rs_digit_scan  one block per digit: exclusive scan of the digit's row over the blocks, and the digit's total
-//   rs_scatter     digit bases from the totals (block scan), then per-round (256 elements) ballot-match ranking inside
-//                  each wave, wave counts through LDS; elements keep their input order inside every digit bucket
-//                  (stable).  Up to two value arrays.
+//   rs_scatter     digit bases from the totals (block scan), per-wave digit counts of the block's four quarters, then
+//                  ballot-match ranking inside each wave with wave-private running slots (no block barrier per round);
+//                  elements keep their input order inside every digit bucket (stable).  Up to two value arrays.
 // Digits are 8 bits wide, or 9 (512 bins, two per thread) when that saves a pass: the depth keys of a frame span
 // bits(far) - bits(near), 27 bits for near 0.1 / far 100 -- three 9-bit passes instead of four 8-bit ones.
 constexpr int RS_THREADS = 256;
 constexpr int RS_MAX_BINS = 512;
 
+// 4096-element tiles from 1 M elements on (measured with the wave-private scatter, 3 M keys: scatter 38 -> 25 us per pass,
+// histogram and digit scan shrink with the block count; at 500 k the small tiles win: 10 against 15 us)
 #ifndef GSR_RS_BIG_MIN
-#define GSR_RS_BIG_MIN (4ll << 20)
+#define GSR_RS_BIG_MIN (1ll << 20)
 #endif
 inline int rs_rounds_for(int64_t n) { return n < GSR_RS_BIG_MIN ? 4 : 16; }     // 1024 or 4096 pairs per block
 inline int rs_digit_bits(int bits) { return (bits + 8) / 9 < (bits + 7) / 8 ? 9 : 8; }
@@ -226,10 +228,20 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(const uint32_
   if (threadIdx.x == 0) digit_total[d] = s_carry;
 }
 
-// Stable scatter with LDS staging.  The block's elements are first placed, digit-bucket by digit-bucket, into an LDS
-// image (ballot-match ranks inside each wave, wave counts through LDS, running per-digit counts across rounds), then
-// written out in image order: consecutive threads write consecutive addresses inside each digit run, so the global
-// stores are coalesced segments instead of 4-byte singles.
+// Stable scatter with LDS staging.  The block's tile of ROUNDS * 256 elements is split into four contiguous quarters, one
+// per wave; every thread keeps its ROUNDS elements in registers.
+//   1. per-wave digit counts of the whole quarter (LDS atomics: only the counts matter);
+//   2. one pass over the digits turns them into each wave's first slot per digit in the block's LDS image (digit-major,
+//      wave-major inside a digit = input order) and the digits' global slots (block scans of the block's counts and of
+//      the digit totals);
+//   3. ranking, 64 elements per wave and round WITHOUT block barriers: lanes holding the same digit find each other by
+//      ballot matching, the lowest takes the digit's running slot of its wave and advances it by the group's size;
+//   4. the image is written out in image order: consecutive threads write consecutive addresses inside each digit
+//      run, so the global stores are coalesced segments instead of 4-byte singles.
+// Elements keep their input order inside every digit bucket (stable).  Up to two value arrays.
+// (Round 2's form ranked 256 elements per round across the four waves: three block barriers and ~26 LDS operations per
+// element, most of them on bins the round never touched; this one has four barriers per BLOCK and ~7 LDS operations per
+// element.)
 template <bool TWO, int ROUNDS, int BITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,   // null -> iota
@@ -241,98 +253,99 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ offsets,
                                                                 const uint32_t* __restrict__ digit_total,
                                                                 uint32_t num_blocks, const uint32_t* __restrict__ n_dev) {
-  constexpr int TILE = ROUNDS * RS_THREADS;
+  constexpr int TILE = ROUNDS * RS_THREADS, QUARTER = ROUNDS * 64;
   constexpr int BINS = 1 << BITS, PER = BINS / RS_THREADS;     // thread t owns the consecutive digits PER t .. PER t + PER - 1
   if (n_dev) n = min(n, *n_dev);
   if (blockIdx.x * (uint32_t)TILE >= n) return;   // uniform over the block; its histogram row is all zeros
   __shared__ uint32_t s_start[BINS];          // first image slot of each digit
   __shared__ uint32_t s_goff[BINS];           // global slot of the digit's first element of this block
-  __shared__ uint32_t s_run[BINS];            // elements of the digit placed by earlier rounds
-  __shared__ uint32_t s_wcnt[4][BINS];        // per-wave digit counts of the current round
+  __shared__ uint32_t s_slot[4][BINS];        // per wave: digit counts of its quarter, then its running image slot per digit
   __shared__ uint32_t s_wave[4], s_wave_t[4];
   __shared__ uint32_t s_key[TILE];
   __shared__ uint32_t s_val[TILE];
   __shared__ uint32_t s_val2[TWO ? TILE : 1];
   const int lane = gsr_lane(), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s_slot[w][threadIdx.x + k * RS_THREADS] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (uint32_t)TILE;
+  const uint32_t block_n = min((uint32_t)TILE, n - base);
+  const uint32_t mine = base + (uint32_t)(wave * QUARTER + lane);   // round r: element mine + 64 r
+  uint32_t key[ROUNDS], val[ROUNDS], val2[TWO ? ROUNDS : 1];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t idx = mine + 64u * r;
+    key[r] = 0u; val[r] = 0u;
+    if (TWO) val2[r] = 0u;
+    if (idx < n) {
+      key[r] = keys_in[idx];
+      val[r] = vals_in ? vals_in[idx] : idx;
+      if (TWO) val2[r] = vals2_in[idx];
+      atomicAdd(&s_slot[wave][(key[r] >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
   {
-    // two block-wide exclusive scans over the digits: this block's counts -> first image slot of each digit; the
-    // digits' totals -> global base of each digit (+ the elements of the digit in earlier blocks = its global slot)
-    uint32_t c[PER], t[PER], mine = 0, mine_t = 0;
+    // block-wide exclusive scans over the digits: this block's counts -> first image slot of each digit (and of each
+    // wave inside it); the digits' totals -> global base of each digit (+ its elements in earlier blocks = global slot)
+    uint32_t c[PER][4], t[PER], here = 0, here_t = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const uint32_t d = PER * threadIdx.x + k;
-      c[k] = counts[(size_t)d * num_blocks + blockIdx.x];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { c[k][w] = s_slot[w][d]; here += c[k][w]; }
       t[k] = digit_total[d];
-      s_run[d] = 0;
-      mine += c[k];
-      mine_t += t[k];
+      here_t += t[k];
     }
-    const uint32_t incl = gsr_wave_scan_incl_u32(mine), incl_t = gsr_wave_scan_incl_u32(mine_t);
+    const uint32_t incl = gsr_wave_scan_incl_u32(here), incl_t = gsr_wave_scan_incl_u32(here_t);
     if (lane == 63) { s_wave[wave] = incl; s_wave_t[wave] = incl_t; }
     __syncthreads();
-    uint32_t at = incl - mine, base = incl_t - mine_t;
+    uint32_t at = incl - here, gbase = incl_t - here_t;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
-      if (w < wave) { at += s_wave[w]; base += s_wave_t[w]; }
+      if (w < wave) { at += s_wave[w]; gbase += s_wave_t[w]; }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const uint32_t d = PER * threadIdx.x + k;
       s_start[d] = at;
-      s_goff[d] = base + offsets[(size_t)d * num_blocks + blockIdx.x];
-      at += c[k];
-      base += t[k];
+      s_goff[d] = gbase + offsets[(size_t)d * num_blocks + blockIdx.x];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s_slot[w][d] = at; at += c[k][w]; }
+      gbase += t[k];
     }
   }
-  const uint32_t base = blockIdx.x * (uint32_t)TILE;
-  const uint32_t block_n = min((uint32_t)TILE, n - base);
+  __syncthreads();
+  uint32_t* my_slots = s_slot[wave];
+#pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const uint32_t round_base = base + r * RS_THREADS;
-    if (round_base >= n) break;                               // uniform over the block
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-#pragma unroll
-      for (int k = 0; k < PER; ++k) s_wcnt[w][threadIdx.x + k * RS_THREADS] = 0;
-    __syncthreads();
-    const uint32_t idx = round_base + threadIdx.x;
-    const bool valid = idx < n;
-    uint32_t key = 0, val = 0, val2 = 0, digit = 0;
-    if (valid) {
-      key = keys_in[idx];
-      val = vals_in ? vals_in[idx] : idx;
-      if (TWO) val2 = vals2_in[idx];
-      digit = (key >> shift) & mask;
-    }
+    const bool valid = mine + 64u * r < n;
+    const uint32_t digit = (key[r] >> shift) & mask;
     uint64_t peers = __ballot(valid);                          // lanes of this wave holding the same digit
 #pragma unroll
     for (int b = 0; b < BITS; ++b) {
-      uint64_t bit = __ballot((digit >> b) & 1u);
+      const uint64_t bit = __ballot((digit >> b) & 1u);
       peers &= ((digit >> b) & 1u) ? bit : ~bit;
     }
     const int rank = gsr_mbcnt(peers);                       // peers below me
-    if (valid && rank == 0) s_wcnt[wave][digit] = (uint32_t)__popcll(peers);
-    __syncthreads();
+    const uint32_t first = valid ? my_slots[digit] : 0u;     // the group reads its digit's running slot ...
+    gsr_wave_lds_fence();
+    if (valid && rank == 0) my_slots[digit] = first + (uint32_t)__popcll(peers);   // ... and its lowest lane advances it
+    gsr_wave_lds_fence();
     if (valid) {
-      uint32_t slot = s_start[digit] + s_run[digit] + (uint32_t)rank;
-#pragma unroll
-      for (int w = 0; w < 4; ++w)
-        if (w < wave) slot += s_wcnt[w][digit];
-      s_key[slot] = key;
-      s_val[slot] = val;
-      if (TWO) s_val2[slot] = val2;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const uint32_t d = threadIdx.x + k * RS_THREADS;
-      s_run[d] += s_wcnt[0][d] + s_wcnt[1][d] + s_wcnt[2][d] + s_wcnt[3][d];
+      const uint32_t slot = first + (uint32_t)rank;
+      s_key[slot] = key[r];
+      s_val[slot] = val[r];
+      if (TWO) s_val2[slot] = val2[r];
     }
   }
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < block_n; e += RS_THREADS) {
-    const uint32_t key = s_key[e];
-    const uint32_t d = (key >> shift) & mask;
+    const uint32_t k = s_key[e];
+    const uint32_t d = (k >> shift) & mask;
     const uint32_t dst = s_goff[d] + (e - s_start[d]);
-    keys_out[dst] = key;
+    keys_out[dst] = k;
     vals_out[dst] = s_val[e];
     if (TWO) vals2_out[dst] = s_val2[e];
   }

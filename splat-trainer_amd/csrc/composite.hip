@@ -200,15 +200,38 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
   // lane 16r+15 ends up with the visibility total of pair (i + {0,2,1,3}[r]) of each group of four
   const uint32_t vis_slot = (uint32_t)(((lane >> 4) & 1) * 2 + (lane >> 5));
   if (begin >= end) return;
-  Splat nxt = load_splat<C, MEDIAN>(rec, sorted_rank, begin);
+  // PF instantiation (frames whose row table has outgrown the caches): the packed splat ids of the NEXT iteration's four
+  // pairs arrive by one scalar load issued at the top of this iteration, so the row fetch of a pair no longer waits for
+  // an index load issued just in front of it (one exposed scalar-load latency per pair; K6 653 -> 602 us at 3M splats;
+  // at 500k it costs 8 SGPRs and 8 %: 191 -> 206 us).  Reads up to 3 words past `end`, inside the list buffer: unused.
+  uint32_t rk[4] = {0u, 0u, 0u, 0u}, rk_next[4] = {0u, 0u, 0u, 0u};
+  Splat nxt;
+  if constexpr (PF) {
+    const uint4 q4 = *reinterpret_cast<const uint4*>(sorted_rank + begin);
+    rk[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.x); rk[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.y);
+    rk[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.z); rk[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.w);
+    nxt = load_splat_packed<C, MEDIAN>(rec, rk[0]);
+  } else {
+    nxt = load_splat<C, MEDIAN>(rec, sorted_rank, begin);
+  }
   for (uint32_t i = begin; i < end; i += 4) {
     if (PF && ((i - tile_start) & (GSR_K6_PREFETCH - 1)) == 0u) fwd_prefetch_step<C>(px, rec, sorted_rank, i, pf_end, lane);
+    if constexpr (PF) {
+      if (i + 4 < end) {
+        const uint4 q4 = *reinterpret_cast<const uint4*>(sorted_rank + i + 4);
+        rk_next[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.x); rk_next[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.y);
+        rk_next[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.z); rk_next[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.w);
+      }
+    }
     float wq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (i + m < end) {                                               // wave-uniform
         const Splat s = nxt;
-        if (i + m + 1 < end) nxt = load_splat<C, MEDIAN>(rec, sorted_rank, i + m + 1);   // prefetch (scalar loads)
+        if (i + m + 1 < end) {                                         // prefetch of the next pair's row (scalar loads)
+          if constexpr (PF) nxt = load_splat_packed<C, MEDIAN>(rec, m < 3 ? rk[m + 1] : rk_next[0]);
+          else nxt = load_splat<C, MEDIAN>(rec, sorted_rank, i + m + 1);
+        }
         const float dxa = fx0 - s.u, dya = fy0 - s.v;
         const v2f dx2 = {dxa, dxa + 8.f};
         const int idx = (int)(i - tile_start) + m + 1;
@@ -258,6 +281,7 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
     const bool live = px.T2[0].x >= rp.T_eps || px.T2[0].y >= rp.T_eps || px.T2[1].x >= rp.T_eps ||
                       px.T2[1].y >= rp.T_eps;
     if (__ballot(live) == 0ull) break;
+    if constexpr (PF) { rk[0] = rk_next[0]; rk[1] = rk_next[1]; rk[2] = rk_next[2]; rk[3] = rk_next[3]; }
   }
 }
 

@@ -67,16 +67,21 @@ typedef struct GsrSegmentsC {
   const uint32_t* tile_seg;   /* [num_tiles,2]: first segment, number of segments (0 = light tile); followed by
                                  [heavy_capacity]: the segments of heavy tiles, listed compactly by the plan */
   const uint32_t* seg_desc;   /* [capacity,4]: tile, list start, list end, index within the tile */
-  const uint32_t* seg_total;  /* two device words: segments of this frame (<= capacity), of them in heavy tiles */
+  const uint32_t* seg_total;  /* GSR_SEG_TOTAL_WORDS device words: [0] segments of this frame (<= capacity), [1] of them in
+                                 heavy tiles, [16 + 32 x + c]: tiles of XCD band x in length class c (the forward pass's launch order) */
   int64_t capacity;           /* from gsr_segment_capacity */
   int64_t heavy_capacity;     /* from gsr_segment_heavy_capacity (<= capacity) */
   float* seg_P;               /* [capacity,256] */
   float* seg_TC;              /* [capacity,256,4], 16-byte aligned: (T, c0, c1, c2) per pixel slot */
   int32_t* seg_last;          /* [capacity,256] */
   float* seg_median;          /* [capacity,256]; NULL unless a median depth image is requested */
+  const uint32_t* tile_order; /* [GSR_TILE_ORDER_WORDS(num_tiles)]: the forward pass's launch order (tiles by XCD band and
+                                 length class, filled by gsr_segment_plan), or NULL: tiles in image order */
 } GsrSegmentsC;
+#define GSR_SEG_TOTAL_WORDS 272
+#define GSR_TILE_ORDER_WORDS(num_tiles) (8 * 32 * (((num_tiles) + 7) / 8))
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 24) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 25) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -251,11 +256,13 @@ int64_t gsr_segment_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cf
 /* ... and on the number of those that belong to heavy tiles (the forward passes A and C launch one block each). */
 int64_t gsr_segment_heavy_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
                                    int32_t num_tiles, int32_t needs_grad);
-/* tile_seg_out [2 num_tiles + heavy_capacity], seg_desc_out [capacity,4], seg_total_out [2] (see GsrSegmentsC);
- * seg_total_out must be ZERO on entry (tiles reserve their slots with integer atomics on it). */
+/* tile_seg_out [2 num_tiles + heavy_capacity], seg_desc_out [capacity,4], seg_total_out [GSR_SEG_TOTAL_WORDS],
+ * tile_order_out [GSR_TILE_ORDER_WORDS(num_tiles)] or NULL (see GsrSegmentsC); seg_total_out must be ZERO on entry
+ * (tiles reserve their slots with integer atomics on it). */
 int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
                      int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, int64_t heavy_capacity,
-                     uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream);
+                     uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out, uint32_t* tile_order_out,
+                     void* stream);
 
 /* ---- K6 alpha-composite forward ------------------------------------------------------------------------- */
 /* image [H,W,C]; final_T [H,W]; last [H,W] int32 = 1 + list position of the last contributing splat;

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -27,7 +27,7 @@ class GsrRasterParamsC(C.Structure):
 class GsrSegmentsC(C.Structure):
   _fields_ = [("tile_seg", C.c_void_p), ("seg_desc", C.c_void_p), ("seg_total", C.c_void_p), ("capacity", C.c_int64),
               ("heavy_capacity", C.c_int64), ("seg_P", C.c_void_p), ("seg_TC", C.c_void_p), ("seg_last", C.c_void_p),
-              ("seg_median", C.c_void_p)]
+              ("seg_median", C.c_void_p), ("tile_order", C.c_void_p)]
 
 
 class GsrFrameC(C.Structure):
@@ -112,7 +112,7 @@ PROTOTYPES = {
     "gsr_segment_thresholds": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _p, _p]),
     "gsr_segment_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "gsr_segment_heavy_capacity": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
-    "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p]),
+    "gsr_segment_plan": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "gsr_composite_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _ps, _i32, _p]),
     "gsr_composite_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _pp, _p, _p, _p, _p, _p, _ps, _p]),
     "gsr_opt_point_weights": (C.c_int, [_p, _p, _i64, _p, _p, _f, _f, _f, _f, _i32, _p, _p]),

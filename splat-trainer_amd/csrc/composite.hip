@@ -139,7 +139,9 @@ __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const
 struct SegDev {
   const uint32_t* tile_seg;    // [num_tiles, 2]: first segment, number of segments (0: short tile) | GSR_SEG_HEAVY
   const uint32_t* seg_desc;    // [capacity, 4]: tile, list start, list end, index within the tile
-  const uint32_t* seg_total;   // device word: number of segments of this frame
+  const uint32_t* seg_total;   // device words (GSR_SEG_TOTAL_WORDS): [0] segments of this frame, [1] of them in heavy tiles,
+                               //   [8 + x] K6's queue head of XCD x, [16 + 32 x + c] tiles of XCD x in length class c
+  const uint32_t* tile_order;  // [8, GSR_TILE_CLASSES, ceil(num_tiles / 8)] tiles per XCD band and length class, or NULL
   float* seg_P;                // [capacity, 256]    product of (1 - alpha) over the segment         (pass A)
   float4* seg_TC;              // [capacity, 256] (T, c0, c1, c2) per pixel slot: T after the segment (< 0: the pixel was
                                //   dead at its entry, pass C) and the colour composited up to the END of the segment
@@ -147,6 +149,26 @@ struct SegDev {
   int* seg_last;               // [capacity, 256]
   float* seg_median;           // [capacity, 256] or NULL
 };
+
+// K6 work distribution.  With one wave per tile and every tile resident at once (1080p: 8160 tiles on 8192 wave slots)
+// a SIMD's finishing time is the sum of whichever eight lists it was dealt, and the launch lasts as long as the unluckiest
+// SIMD: measured 4.6 of 8 wave slots occupied on average, the VALUs 65 % busy -- and in image order a SIMD's eight tiles
+// are neighbours, all long or all short.  So the plan kernel files every (not heavy) tile under its XCD band (the
+// contiguous tile range gsr_xcd_remap gives that XCD: neighbouring tiles keep sharing an L2) and one of 32 length classes
+// (eighths of the mean list length), and block b of the forward launch takes the (b / 8)-th tile of band b % 8 counted
+// from the longest class down: the dispatcher deals consecutive blocks across the SIMDs, so every SIMD gets its share of
+// each class.  K6 195 -> 183 us at 500k splats, 596 -> 528 us at 3M (same box).  Which slot composites a tile changes
+// nothing the tile computes: results are bit-identical to the image-order launch.  (Measured and not kept: limiting the
+// residency to 4-7 waves per SIMD with dummy LDS so that the dispatcher hands out the short tiles dynamically: 213-244 us;
+// reversing every other round of 32-1024 blocks: no change.)
+#define GSR_TILE_CLASSES 32
+#define GSR_SEG_CLASS_COUNT(band) (16u + GSR_TILE_CLASSES * (band))     // word of seg_total: band's first class count
+__host__ __device__ inline int gsr_tile_band(int t, int n) {            // inverse of gsr_xcd_remap: the XCD that owns tile t
+  const int q = n >> 3, r = n & 7;
+  if (t < r * (q + 1)) return t / (q + 1);
+  return q ? r + (t - r * (q + 1)) / q : 7;
+}
+__host__ __device__ inline int gsr_tile_band_stride(int n) { return (n + 7) >> 3; }
 
 // per-lane pixel state of the forward walk: pixel p = 2h + i, half h (rows py0 + 8h), side i (cols px0 + 8i)
 template <int C>
@@ -343,9 +365,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
                                                            float* __restrict__ image, float* __restrict__ final_T,
                                                            int* __restrict__ last, float* __restrict__ median,
                                                            float* __restrict__ vis_partial,
-                                                           float* __restrict__ pair_vis, SegDev seg) {
-  if ((int)blockIdx.x >= num_tiles) {                                // extra blocks: pass A of the heavy tiles' segments
-    const uint32_t h = blockIdx.x - (uint32_t)num_tiles;             // index into the plan's compact list of them
+                                                           float* __restrict__ pair_vis, SegDev seg, int tile_blocks) {
+  if ((int)blockIdx.x >= tile_blocks) {                              // extra blocks: pass A of the heavy tiles' segments
+    const uint32_t h = blockIdx.x - (uint32_t)tile_blocks;           // index into the plan's compact list of them
     if (h < seg.seg_total[1]) {
       const uint32_t sidx = (seg.tile_seg + 2 * (size_t)num_tiles)[h];
       if (sidx != 0xFFFFFFFFu) {
@@ -355,10 +377,30 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
     }
     return;
   }
-  const int tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
+  const int lane = (int)threadIdx.x;
+  int tile;
+  if (seg.tile_order) {
+    // ordered form (see GSR_TILE_CLASSES): lane l < 32 gets the number of this band's tiles in classes 31 .. 31 - l
+    const uint32_t band = blockIdx.x & 7u;
+    uint32_t t = blockIdx.x >> 3;
+    uint32_t upto = lane < GSR_TILE_CLASSES ? seg.seg_total[GSR_SEG_CLASS_COUNT(band) + (GSR_TILE_CLASSES - 1 - lane)] : 0u;
+#pragma unroll
+    for (int o = 1; o < GSR_TILE_CLASSES; o <<= 1) {
+      const uint32_t below = (uint32_t)__shfl_up((int)upto, o, 64);
+      if (lane >= o) upto += below;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)upto, GSR_TILE_CLASSES - 1);
+    if (t >= total) return;                                           // past the band's last tile
+    const uint64_t longer = __ballot(lane < GSR_TILE_CLASSES && t < upto);
+    const int l = __builtin_ctzll(longer);
+    const uint32_t before = l ? (uint32_t)__builtin_amdgcn_readlane((int)upto, l - 1) : 0u;
+    tile = (int)seg.tile_order[((size_t)band * GSR_TILE_CLASSES + (size_t)(GSR_TILE_CLASSES - 1 - l)) *
+                                   (size_t)gsr_tile_band_stride(num_tiles) + (t - before)];
+  } else {
+    tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
+  }
   const uint32_t tseg = seg.tile_seg ? seg.tile_seg[2 * tile + 1] : 0u;
   if (tseg & GSR_SEG_HEAVY) return;                                   // heavy tile: passes A, C, D composite it
-  const int lane = (int)threadIdx.x;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
@@ -769,11 +811,13 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
                                                            uint32_t capacity, uint32_t heavy_capacity,
                                                            uint32_t* __restrict__ tile_seg,
                                                            uint32_t* __restrict__ seg_desc,
-                                                           uint32_t* __restrict__ seg_total) {
+                                                           uint32_t* __restrict__ seg_total,
+                                                           uint32_t* __restrict__ tile_order) {
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (t >= num_tiles) return;
   uint32_t seg_pairs, heavy_min;
-  segment_thresholds(seg_cfg, heavy_cfg, O_dev ? (int64_t)*O_dev : O, num_tiles, needs_grad, &seg_pairs, &heavy_min);
+  const int64_t O_now = O_dev ? (int64_t)*O_dev : O;
+  segment_thresholds(seg_cfg, heavy_cfg, O_now, num_tiles, needs_grad, &seg_pairs, &heavy_min);
   const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
   // a heavy tile's segments are also FORWARD work units (alpha-product pass + a prologue over the preceding segments):
   // about 256 pairs each and at most ~128 per tile; a long tile's segments are only checkpoints: seg_pairs each
@@ -807,6 +851,13 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
   }
   tile_seg[2 * t] = at;
   tile_seg[2 * t + 1] = n | ((n && heavy) ? GSR_SEG_HEAVY : 0u);
+  if (tile_order && !(n && heavy)) {               // K6's queues (heavy tiles are composited by the segment passes)
+    const uint32_t mean = (uint32_t)max((int64_t)1, O_now / num_tiles);
+    const uint32_t cls = min((uint32_t)(GSR_TILE_CLASSES - 1), len * 8u / mean);
+    const uint32_t band = (uint32_t)gsr_tile_band(t, num_tiles);
+    const uint32_t slot = atomicAdd(seg_total + GSR_SEG_CLASS_COUNT(band) + cls, 1u);
+    tile_order[((size_t)band * GSR_TILE_CLASSES + cls) * (size_t)gsr_tile_band_stride(num_tiles) + slot] = (uint32_t)t;
+  }
   for (uint32_t j = 0; j < n; ++j) {
     uint32_t* d = seg_desc + 4 * (size_t)(at + j);
     d[0] = (uint32_t)t; d[1] = a + j * seg_t; d[2] = min(a + (j + 1) * seg_t, a + len); d[3] = j;
@@ -817,9 +868,11 @@ inline SegDev to_segdev(const GsrSegmentsC* sg) {
   SegDev d;
   if (sg) {
     d.tile_seg = sg->tile_seg; d.seg_desc = sg->seg_desc; d.seg_total = sg->seg_total; d.seg_P = sg->seg_P;
+    d.tile_order = sg->tile_order;
     d.seg_TC = reinterpret_cast<float4*>(sg->seg_TC); d.seg_last = sg->seg_last; d.seg_median = sg->seg_median;
   } else {
     d.tile_seg = nullptr; d.seg_desc = nullptr; d.seg_total = nullptr; d.seg_P = nullptr; d.seg_TC = nullptr;
+    d.tile_order = nullptr;
     d.seg_last = nullptr; d.seg_median = nullptr;
   }
   return d;
@@ -883,7 +936,8 @@ int64_t gsr_segment_heavy_capacity(int64_t O, int32_t O_is_bound, int32_t seg_pa
 
 int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_pairs_cfg, int32_t heavy_min_cfg,
                      int32_t needs_grad, int64_t O, const uint32_t* O_dev, int64_t capacity, int64_t heavy_capacity,
-                     uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out, void* stream_) {
+                     uint32_t* tile_seg_out, uint32_t* seg_desc_out, uint32_t* seg_total_out, uint32_t* tile_order_out,
+                     void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (num_tiles <= 0 || capacity <= 0 || capacity > 0x7fffffffll || (O < 0 && !O_dev)) return GSR_ERR_INVALID_ARGUMENT;
   if (heavy_capacity < 0 || heavy_capacity > capacity) return GSR_ERR_INVALID_ARGUMENT;
@@ -892,7 +946,7 @@ int gsr_segment_plan(const uint32_t* tile_range, int32_t num_tiles, int32_t seg_
   segment_plan_kernel<<<(num_tiles + 255) / 256, 256, 0, stream>>>(tile_range, num_tiles, seg_pairs_cfg, heavy_min_cfg,
                                                                   needs_grad, O, O_dev, (uint32_t)capacity,
                                                                   (uint32_t)heavy_capacity, tile_seg_out, seg_desc_out,
-                                                                  seg_total_out);
+                                                                  seg_total_out, tile_order_out);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
@@ -913,12 +967,13 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
   if (!seg_ok(segments_host, med)) return GSR_ERR_INVALID_ARGUMENT;
   const SegDev seg = to_segdev(segments_host);
   const int cap = segments_host ? (int)segments_host->heavy_capacity : 0;   // blocks of the heavy-tile passes
+  const int tb = seg.tile_order ? (nt + 7) / 8 * 8 : nt;     // tile blocks (ordered form: whole rounds over the 8 XCDs)
 #define GSR_LAUNCH_FWD2(CC, VV, MM, PP)                                                                                \
   do {                                                                                                                 \
-    composite_fwd_kernel<CC, VV, MM, PP><<<nt + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, \
+    composite_fwd_kernel<CC, VV, MM, PP><<<tb + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, \
                                                                       tx, nt, rp, image_out, final_T_out, last_out,    \
                                                                       median_depth_out, vis_partial_out, pair_vis_out, \
-                                                                      seg);                                            \
+                                                                      seg, tb);                                        \
     if (cap) {                                                                                                         \
       seg_composite_kernel<CC, VV, MM, PP><<<cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H,    \
                                                                    tx, nt, rp, vis_partial_out, pair_vis_out, seg);    \

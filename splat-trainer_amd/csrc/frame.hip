@@ -70,7 +70,7 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
   p->zero_begin = 0;
   p->prune_cost = out.take(4 * N);
   p->split_score = out.take(4 * N);
-  p->counts = out.take(4 * 8);                 // [M, O, overflow flag, segments, heavy segments, -, -, -]
+  p->counts = out.take(4 * (3 + GSR_SEG_TOTAL_WORDS));   // [M, O, overflow flag, then the segment plan's counters]
   p->tile_range = out.take(4 * 2 * T);
   p->vis_partial = vis_partial ? out.take(4 * cap) : -1;
   p->zero_bytes = out.at;
@@ -104,7 +104,7 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
       if (hc > sc) hc = sc;
       p->seg_capacity = sc;
       p->seg_heavy_capacity = hc;
-      p->seg_tables = out.take(4 * (2 * T + hc + 4 * sc));
+      p->seg_tables = out.take(4 * (2 * T + hc + 4 * sc + GSR_TILE_ORDER_WORDS(T)));
       const int64_t planes = 5 + (f->want_median ? 1 : 0);
       p->seg_pix = out.take(4 * planes * sc * 256);
       p->seg_last = out.take(4 * sc * 256);
@@ -245,12 +245,14 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
       uint32_t* tile_seg = tables;
       uint32_t* seg_desc = tables + 2 * (int64_t)T + p->seg_heavy_capacity;
       uint32_t* seg_total = counts + 3;
+      uint32_t* tile_order = seg_desc + 4 * p->seg_capacity;
       GSR_TRY(gsr_segment_plan(tile_range, T, f->seg_pairs, f->seg_min_pairs, f->needs_grad ? 1 : 0, cap, O_dev,
-                               p->seg_capacity, p->seg_heavy_capacity, tile_seg, seg_desc, seg_total, stream_));
+                               p->seg_capacity, p->seg_heavy_capacity, tile_seg, seg_desc, seg_total, tile_order, stream_));
       float* pix = at<float>(out, p->seg_pix);
       res->segments.tile_seg = tile_seg;
       res->segments.seg_desc = seg_desc;
       res->segments.seg_total = seg_total;
+      res->segments.tile_order = tile_order;
       res->segments.capacity = p->seg_capacity;
       res->segments.heavy_capacity = p->seg_heavy_capacity;
       res->segments.seg_TC = pix;

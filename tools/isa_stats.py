@@ -65,7 +65,7 @@ def kernels(asm: str) -> dict:
       meta[name] = dict(vgpr=num("vgpr_count"), sgpr=num("sgpr_count"), scratch=num("private_segment_fixed_size"),
                         lds=num("group_segment_fixed_size"))
   for name in meta:
-    m = re.search(rf"^{re.escape(name)}:.*?\n(.*?)s_endpgm", asm, flags=re.S | re.M)
+    m = re.search(rf"^{re.escape(name)}:.*?\n(.*?)^\.Lfunc_end", asm, flags=re.S | re.M)   # (a kernel may hold several s_endpgm)
     meta[name]["body"] = m.group(1).splitlines() if m else []
   return meta
 

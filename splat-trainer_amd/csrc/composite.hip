@@ -160,7 +160,9 @@ struct SegDev {
 // each class.  K6 195 -> 183 us at 500k splats, 596 -> 528 us at 3M (same box).  Which slot composites a tile changes
 // nothing the tile computes: results are bit-identical to the image-order launch.  (Measured and not kept: limiting the
 // residency to 4-7 waves per SIMD with dummy LDS so that the dispatcher hands out the short tiles dynamically: 213-244 us;
-// reversing every other round of 32-1024 blocks: no change.)
+// reversing every other round of 32-1024 blocks: no change; 4-8 persistent waves per SIMD pulling tiles from per-band
+// queue heads with integer atomics, tile-only arguments re-read from the kernel-argument segment so that the walk keeps
+// its registers: 190-228 us against 185, 525-590 against 526 at 3M.)
 #define GSR_TILE_CLASSES 32
 #define GSR_SEG_CLASS_COUNT(band) (16u + GSR_TILE_CLASSES * (band))     // word of seg_total: band's first class count
 __host__ __device__ inline int gsr_tile_band(int t, int n) {            // inverse of gsr_xcd_remap: the XCD that owns tile t
@@ -169,6 +171,24 @@ __host__ __device__ inline int gsr_tile_band(int t, int n) {            // inver
   return q ? r + (t - r * (q + 1)) / q : 7;
 }
 __host__ __device__ inline int gsr_tile_band_stride(int n) { return (n + 7) >> 3; }
+
+// The tile of block b in the ordered launch (see GSR_TILE_CLASSES), or -1 past the end of the band's list.
+__device__ __forceinline__ int ordered_tile(const SegDev& seg, int num_tiles, uint32_t b, int lane) {
+  const uint32_t band = b & 7u, t = b >> 3;
+  // lane l < 32 gets the number of this band's tiles in classes 31 .. 31 - l
+  uint32_t upto = lane < GSR_TILE_CLASSES ? seg.seg_total[GSR_SEG_CLASS_COUNT(band) + (GSR_TILE_CLASSES - 1 - lane)] : 0u;
+#pragma unroll
+  for (int o = 1; o < GSR_TILE_CLASSES; o <<= 1) {
+    const uint32_t below = (uint32_t)__shfl_up((int)upto, o, 64);
+    if (lane >= o) upto += below;
+  }
+  const uint64_t longer = __ballot(lane < GSR_TILE_CLASSES && t < upto);
+  if (longer == 0ull) return -1;
+  const int l = __builtin_ctzll(longer);
+  const uint32_t before = l ? (uint32_t)__builtin_amdgcn_readlane((int)upto, l - 1) : 0u;
+  return (int)seg.tile_order[((size_t)band * GSR_TILE_CLASSES + (size_t)(GSR_TILE_CLASSES - 1 - l)) *
+                                 (size_t)gsr_tile_band_stride(num_tiles) + (t - before)];
+}
 
 // per-lane pixel state of the forward walk: pixel p = 2h + i, half h (rows py0 + 8h), side i (cols px0 + 8i)
 template <int C>
@@ -380,22 +400,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
   const int lane = (int)threadIdx.x;
   int tile;
   if (seg.tile_order) {
-    // ordered form (see GSR_TILE_CLASSES): lane l < 32 gets the number of this band's tiles in classes 31 .. 31 - l
-    const uint32_t band = blockIdx.x & 7u;
-    uint32_t t = blockIdx.x >> 3;
-    uint32_t upto = lane < GSR_TILE_CLASSES ? seg.seg_total[GSR_SEG_CLASS_COUNT(band) + (GSR_TILE_CLASSES - 1 - lane)] : 0u;
-#pragma unroll
-    for (int o = 1; o < GSR_TILE_CLASSES; o <<= 1) {
-      const uint32_t below = (uint32_t)__shfl_up((int)upto, o, 64);
-      if (lane >= o) upto += below;
-    }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)upto, GSR_TILE_CLASSES - 1);
-    if (t >= total) return;                                           // past the band's last tile
-    const uint64_t longer = __ballot(lane < GSR_TILE_CLASSES && t < upto);
-    const int l = __builtin_ctzll(longer);
-    const uint32_t before = l ? (uint32_t)__builtin_amdgcn_readlane((int)upto, l - 1) : 0u;
-    tile = (int)seg.tile_order[((size_t)band * GSR_TILE_CLASSES + (size_t)(GSR_TILE_CLASSES - 1 - l)) *
-                                   (size_t)gsr_tile_band_stride(num_tiles) + (t - before)];
+    tile = ordered_tile(seg, num_tiles, blockIdx.x, lane);
+    if (tile < 0) return;                                             // past the band's last tile
   } else {
     tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
   }
@@ -559,6 +565,9 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
 #ifndef GSR_K7_SEG_GROUP_LOG2
 #define GSR_K7_SEG_GROUP_LOG2 5
 #endif
+#ifndef GSR_K7_SEG_FIRST
+#define GSR_K7_SEG_FIRST 1
+#endif
 template <int C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES, GSR_K7_WAVES))) void composite_bwd_kernel(const float* __restrict__ rec,
                                                            const uint32_t* __restrict__ sorted_rank,
@@ -571,14 +580,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
                                                            const float* __restrict__ dL_dimage,
                                                            const float* __restrict__ image,
                                                            float* __restrict__ partial, SegDev seg,
-                                                           uint32_t seg_capacity) {
+                                                           uint32_t seg_capacity, uint32_t seg_blocks) {
   // A block walks tile-relative list positions [lo, hi) in reverse: a short tile's whole list, or -- extra blocks of
   // the launch -- one segment of a longer tile, entered with that segment's own end state from the forward pass.
   int tile, lo = 0, seg_hi = 0x7fffffff;
   uint32_t sidx = 0u;
+#if GSR_K7_SEG_FIRST
+  // segments (the longest work units) first, then the unsegmented tiles longest class first: the launch has several
+  // times more blocks than the chip has slots, the dispatcher hands them out in index order, so what starts last -- and
+  // sets the length of the launch's tail -- should be the shortest units
+  const bool is_seg = blockIdx.x < seg_blocks;
+  if (is_seg) {
+    sidx = blockIdx.x;
+#else
   const bool is_seg = (int)blockIdx.x >= num_tiles;
   if (is_seg) {
     sidx = blockIdx.x - (uint32_t)num_tiles;
+#endif
 #if GSR_K7_SEGMAP == 2
     sidx = gsr_xcd_group_remap(sidx, GSR_K7_SEG_GROUP_LOG2);     // a tile's segments share an XCD (and its L2)
     if (sidx >= min(seg.seg_total[0], seg_capacity)) return;     // (the grid is rounded up past the tables' capacity)
@@ -594,7 +612,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
     lo = (int)(d[1] - tstart);
     seg_hi = (int)(d[2] - tstart);
   } else {
+#if GSR_K7_SEG_FIRST
+    const uint32_t b = blockIdx.x - seg_blocks;                       // (seg_blocks is a multiple of 8: same XCD)
+    if (seg.tile_order) {
+      tile = ordered_tile(seg, num_tiles, b, (int)threadIdx.x);
+      if (tile < 0) return;
+    } else {
+      if ((int)b >= num_tiles) return;
+      tile = gsr_xcd_remap((int)b, num_tiles);
+    }
+#else
     tile = gsr_xcd_remap((int)blockIdx.x, num_tiles);
+#endif
     if (seg.tile_seg && seg.tile_seg[2 * tile + 1] != 0u) return;     // segmented tile: its segment blocks handle it
   }
   const int lane = (int)threadIdx.x;
@@ -968,12 +997,14 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
   const SegDev seg = to_segdev(segments_host);
   const int cap = segments_host ? (int)segments_host->heavy_capacity : 0;   // blocks of the heavy-tile passes
   const int tb = seg.tile_order ? (nt + 7) / 8 * 8 : nt;     // tile blocks (ordered form: whole rounds over the 8 XCDs)
+#define GSR_LAUNCH_TILES(CC, VV, MM, PP)                                                                               \
+  composite_fwd_kernel<CC, VV, MM, PP><<<tb + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H,   \
+                                                                    tx, nt, rp, image_out, final_T_out, last_out,      \
+                                                                    median_depth_out, vis_partial_out, pair_vis_out,   \
+                                                                    seg, tb)
 #define GSR_LAUNCH_FWD2(CC, VV, MM, PP)                                                                                \
   do {                                                                                                                 \
-    composite_fwd_kernel<CC, VV, MM, PP><<<tb + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H, \
-                                                                      tx, nt, rp, image_out, final_T_out, last_out,    \
-                                                                      median_depth_out, vis_partial_out, pair_vis_out, \
-                                                                      seg, tb);                                        \
+    GSR_LAUNCH_TILES(CC, VV, MM, PP);                                                                                  \
     if (cap) {                                                                                                         \
       seg_composite_kernel<CC, VV, MM, PP><<<cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H,    \
                                                                    tx, nt, rp, vis_partial_out, pair_vis_out, seg);    \
@@ -999,6 +1030,7 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
 #undef GSR_DISPATCH_FWD
 #undef GSR_LAUNCH_FWD
 #undef GSR_LAUNCH_FWD2
+#undef GSR_LAUNCH_TILES
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }
@@ -1018,10 +1050,12 @@ int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const 
   const SegDev seg = to_segdev(segments_host);
   // segment blocks: rounded up to the XCD grouping of gsr_xcd_group_remap (blocks past seg_total return)
   const int seg_round = 8 << GSR_K7_SEG_GROUP_LOG2;
-  const int grid = nt + (segments_host ? (int)((segments_host->capacity + seg_round - 1) / seg_round * seg_round) : 0);
-  if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, (uint32_t)(segments_host ? segments_host->capacity : 0));
-  else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, (uint32_t)(segments_host ? segments_host->capacity : 0));
-  else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, (uint32_t)(segments_host ? segments_host->capacity : 0));
+  const uint32_t seg_blocks = segments_host ? (uint32_t)((segments_host->capacity + seg_round - 1) / seg_round * seg_round) : 0u;
+  const uint32_t seg_cap = (uint32_t)(segments_host ? segments_host->capacity : 0);
+  const int grid = (nt + 7) / 8 * 8 + (int)seg_blocks;
+  if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, seg_cap, seg_blocks);
+  else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, seg_cap, seg_blocks);
+  else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, seg_cap, seg_blocks);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -120,7 +120,9 @@ def point_state_update(state, idx, screen_scale=None, visibility=None, split_sco
   M = int(idx.shape[0]) if idx is not None else int(given[0].shape[0])
   if M == 0:
     return state
-  f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+  # (float32 contiguous inputs -- what the renderer delivers -- pass through untouched: this runs once per camera)
+  f32 = lambda t: t if (t is None or (t.dtype is torch.float32 and t.is_contiguous())) else \
+      t.detach().to(torch.float32).contiguous()
   scale = f32(screen_scale)
   cols = 2 if (scale is not None and scale.dim() == 2) else 1
   for t in (state.prune_cost, state.split_score, state.max_scale_px, state.visibility):
@@ -131,7 +133,7 @@ def point_state_update(state, idx, screen_scale=None, visibility=None, split_sco
   if visible_sum is not None and not (visible_sum.is_cuda and visible_sum.dtype == torch.float32 and
                                       visible_sum.is_contiguous() and visible_sum.shape == state.visibility.shape):
     raise ValueError("visible_sum must be a contiguous float32 CUDA tensor shaped like state.visibility")
-  _lib.check(lib.gsr_point_state_add(_p(idx.contiguous()) if idx is not None else None, _p(scale), cols,
+  _lib.check(lib.gsr_point_state_add(_p(idx if idx.is_contiguous() else idx.contiguous()) if idx is not None else None, _p(scale), cols,
                                      _p(f32(visibility)), _p(f32(split_score)), _p(f32(prune_cost)), M,
                                      float(split_alpha), float(prune_alpha), _p(state.prune_cost), _p(state.split_score),
                                      _p(state.max_scale_px), _p(state.points_in_view), _p(state.visibility),

@@ -55,7 +55,7 @@ class _SSIMFn(torch.autograd.Function):
     if maps is None:
       raise _lib.GsplatHipError("fused_ssim(train=False) result cannot be back-propagated")
     B, Cc, H, W = x.shape
-    gs = g.detach().to(torch.float32).reshape(1).contiguous()
+    gs = g if (g.dtype is torch.float32 and g.is_contiguous()) else g.detach().to(torch.float32).contiguous()   # one scalar
     d = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device)
     _lib.check(lib.gsr_ssim_backward(_ptr(x), _ptr(y), _strides(x), _strides(y), _strides(d), B, Cc, H, W,
                                      _ptr(maps[0]), _ptr(maps[1]), _ptr(maps[2]), _ptr(gs), _ptr(d), _stream()),
@@ -81,8 +81,9 @@ class _PixelLossFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, image, target, kind, lo, hi):
     lib = _lib.load()
-    x = image.detach().to(torch.float32).contiguous()
-    t = target.detach().to(torch.float32).expand_as(x).contiguous()
+    plain = lambda a: a.dtype is torch.float32 and a.is_contiguous()
+    x = image.detach() if plain(image) else image.detach().to(torch.float32).contiguous()
+    t = target if (plain(target) and target.shape == x.shape) else target.detach().to(torch.float32).expand_as(x).contiguous()
     n = x.numel()
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     ws_bytes = lib.gsr_pixel_loss_workspace_bytes(n)

@@ -81,8 +81,14 @@ class KernelTimer:
 KERNEL_TIMER: Optional[KernelTimer] = None
 
 
-def _ptr(t: Optional[torch.Tensor]):
-  if t is None or t.numel() == 0:
+def _ptr(t):
+  """ctypes pointer of a tensor's data, or of a raw device address (an int: buffers of the frame arena that are only ever
+  handed to kernels are kept as addresses, see _run_frame), or None."""
+  if t is None:
+    return None
+  if isinstance(t, int):
+    return C.c_void_p(t) if t else None
+  if t.numel() == 0:
     return None
   return C.c_void_p(t.data_ptr())
 
@@ -100,6 +106,8 @@ def _require_device(*tensors: torch.Tensor):
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
+  if t.dtype is torch.float32 and t.is_contiguous():
+    return t.detach()
   return t.detach().to(torch.float32).contiguous()
 
 
@@ -134,14 +142,15 @@ SPECULATE = os.environ.get("GSPLAT_HIP_NO_SPECULATION", "0") != "1"
 
 
 def _readback_slot(device):
-  """(pinned int32[8] landing buffer, event) of this thread for ``device``; the event has been recorded once so that
-  its native handle exists (native callers record it themselves)."""
+  """(pinned int32[8] landing buffer, event, the buffer as a ctypes array) of this thread for ``device``; the event has
+  been recorded once so that its native handle exists (native callers record it themselves)."""
   pool = _TLS.__dict__.setdefault("readback", {})
   key = device.index
   if key not in pool:
     event = torch.cuda.Event()
     event.record(_lib.current_stream())
-    pool[key] = (torch.empty(8, dtype=torch.int32).pin_memory(), event)
+    host = torch.empty(8, dtype=torch.int32).pin_memory()
+    pool[key] = (host, event, (C.c_int32 * 8).from_address(host.data_ptr()))    # + the same words as a ctypes array
   return pool[key]
 
 
@@ -171,7 +180,7 @@ def _start_readback(words: torch.Tensor):
   The two sizes the path cannot know in advance (visible splats, tile overlaps) come back this way: whatever is
   enqueued between this call and ``wait()`` runs while the host blocks on the COPY's event, not on the stream, so the
   GPU does not idle through the host's round trip.  One pinned landing buffer + event per thread and device."""
-  host, event = _readback_slot(words.device)
+  host, event, _ = _readback_slot(words.device)
   n = words.numel()
   host[:n].copy_(words, non_blocking=True)
   event.record(_lib.current_stream())
@@ -472,11 +481,17 @@ class _RasterFn(torch.autograd.Function):
     return d_g2d.to(ctx.in_dtypes[0]), d_feat.to(ctx.in_dtypes[1]), None, None, None
 
 
-def _arena_view(arena: torch.Tensor, offset: int, shape, dtype) -> torch.Tensor:
-  n = 1
-  for d in shape:
-    n *= int(d)
-  return arena[offset:offset + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+def _arena_view(arena: torch.Tensor, offset: int, shape, dtype=torch.float32) -> torch.Tensor:
+  """A contiguous tensor of ``shape`` at byte ``offset`` of the uint8 arena (one as_strided call on a typed alias)."""
+  typed = arena.view(dtype)
+  size = typed.element_size()
+  if len(shape) == 1:
+    strides = (1,)
+  elif len(shape) == 2:
+    strides = (int(shape[1]), 1)
+  else:
+    strides = (int(shape[1]) * int(shape[2]), int(shape[2]), 1)
+  return torch.as_strided(typed, shape, strides, offset // size)
 
 
 def _pair_capacity(dev_index, N: int):
@@ -506,7 +521,7 @@ def _run_frame(frame: "_lib.GsrFrameC", st: _RasterState, dev, rows_bound: int, 
     out = torch.empty(plan.out_bytes, dtype=torch.uint8, device=dev)
     work = torch.empty(plan.work_bytes, dtype=torch.uint8, device=dev)
     ev = timer.pair("composite_forward") if timer is not None else (None, None)
-    host, ready = _readback_slot(dev)
+    host, ready, host_words = _readback_slot(dev)
     _lib.check(lib.gsr_frame_forward(C.byref(frame), C.byref(plan), C.c_void_p(out.data_ptr()),
                                      C.c_void_p(work.data_ptr()), C.byref(res), C.c_void_p(host.data_ptr()),
                                      C.c_void_p(ready.cuda_event), ev[0], ev[1], _stream()), "gsr_frame_forward")
@@ -514,7 +529,7 @@ def _run_frame(frame: "_lib.GsrFrameC", st: _RasterState, dev, rows_bound: int, 
     # the frame's only host wait: on the copy the driver issued right behind the scan, with the emit, the tile sort and
     # the composite already enqueued behind it -- the device works on while the host shapes the tensors and moves on
     ready.synchronize()
-    M, O, overflow = host[:3].tolist()
+    M, O, overflow = host_words[0], host_words[1], host_words[2]
     if overflow or O < 0:      # the guard fires before a 32-bit wrap can go unnoticed (screen-filling splats at 4K)
       raise _lib.GsplatHipError("tile overlap count reached 2^31: the (tile, splat) lists are addressed with 32 bits")
     if O <= capacity:
@@ -525,32 +540,34 @@ def _run_frame(frame: "_lib.GsrFrameC", st: _RasterState, dev, rows_bound: int, 
   guesses[dev.index] = min(max(O + O // 4 + 4096, raw_guess - raw_guess // 64), 0x7fffffff)   # grows at once, decays slowly
   if projected:
     M = N
-  num_tiles = ((W + 15) // 16) * ((H + 15) // 16)
-  V = lambda off, shape, dtype=torch.float32: _arena_view(out, off, shape, dtype)
+  # Buffers only kernels ever see are kept as device addresses (no tensor objects: ten views a frame cost the host more
+  # than the small frames' kernels take); the arena itself stays alive through st.segment_buffers.
+  base = out.data_ptr()
+  out_f = out.view(torch.float32)
+  V = lambda off, shape, strides: torch.as_strided(out_f, shape, strides, off >> 2)
   st.M, st.O = M, O
-  st.rows = V(plan.rows, (N, ROW_FLOATS))[:M]
-  st.screen_scale = V(plan.screen_scale, (N, 2))[:M]
+  st.rows = V(plan.rows, (M, ROW_FLOATS), (ROW_FLOATS, 1))
+  st.screen_scale = V(plan.screen_scale, (M, 2), (2, 1))
   if res.order >= 0:
-    st.order = V(res.order, (N,), torch.int32)
-  st.count, st.offsets = V(plan.count, (N,), torch.int32), V(plan.offsets, (N,), torch.int32)
-  st.sorted_splat = V(res.sorted_splat, (capacity,), torch.int32)
-  st.sorted_inst = V(res.sorted_inst, (capacity,), torch.int32)
-  st.tile_range = V(plan.tile_range, (num_tiles, 2), torch.int32)
+    st.order = base + res.order
+  st.count, st.offsets = base + plan.count, base + plan.offsets
+  st.sorted_splat, st.sorted_inst = base + res.sorted_splat, base + res.sorted_inst
+  st.tile_range = base + plan.tile_range
   keep = st.compute_visibility or st.needs_grad
-  st.vis_partial = V(plan.vis_partial, (capacity,)) if keep else None
-  st.pair_vis = V(plan.pair_vis, (capacity,)) if keep else None
-  st.final_T, st.last = V(plan.final_T, (H, W)), V(plan.last, (H, W), torch.int32)
-  st.median = V(plan.median, (H, W)) if st.want_median else None
-  st.visibility = V(plan.visibility, (N,))[:M]
-  st.prune_cost, st.split_score = V(plan.prune_cost, (N,))[:M], V(plan.split_score, (N,))[:M]
+  st.vis_partial = base + plan.vis_partial if keep else None
+  st.pair_vis = base + plan.pair_vis if keep else None
+  st.final_T, st.last = V(plan.final_T, (H, W), (W, 1)), base + plan.last
+  st.median = V(plan.median, (H, W), (W, 1)) if st.want_median else None
+  st.visibility = V(plan.visibility, (M,), (1,))
+  st.prune_cost, st.split_score = V(plan.prune_cost, (M,), (1,)), V(plan.split_score, (M,), (1,))
   st.vis_capacity = capacity
   if not st.compute_visibility:
     st.visibility.zero_()
   st.vis_ready = not (st.compute_visibility and st.needs_grad)    # without gradients the driver reduced it already
   st.segments = _lib.GsrSegmentsC.from_buffer_copy(res.segments) if res.has_segments else None
   st.segment_buffers = (out,)
-  image = V(plan.image, (H, W, C_))
-  st.image = image.detach() if st.needs_grad else None
+  image = V(plan.image, (H, W, C_), (W * C_, C_, 1))
+  st.image = base + plan.image if st.needs_grad else None
   return out, plan, M, image
 
 
@@ -590,11 +607,11 @@ class _FrameFn(torch.autograd.Function):
       side, fork, join = _side_stream(dev)
       frame.side_stream, frame.event_fork, frame.event_join = side.cuda_stream, fork.cuda_event, join.cuda_event
     out, plan, M, image = _run_frame(frame, st, dev, N, projected=False)
-    indexes = _arena_view(out, plan.indexes, (N,), torch.int64)[:M]
+    indexes = _arena_view(out, plan.indexes, (M,), torch.int64)
     rows = st.rows
     ctx.save_for_backward(pos, ls, rot, al, sh, indexes, T, proj, cam)
     ctx.set_materialize_grads(False)       # unused outputs (gaussians2d / depth, usually) arrive as None
-    ctx.st, ctx.jac = st, (_arena_view(out, plan.jacobian, (N, 9), torch.float32)[:M] if plan.jacobian >= 0 else None)
+    ctx.st, ctx.jac = st, (_arena_view(out, plan.jacobian, (M, 9)) if plan.jacobian >= 0 else None)
     ctx.grad_out, ctx.sh_out = grad_out, sh_out
     ctx.in_dtypes = (position.dtype, log_scaling.dtype, rotation.dtype, alpha_logit.dtype, feature.dtype)
     ctx.mark_non_differentiable(indexes)

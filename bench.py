@@ -420,6 +420,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "untimed_prewarm_steps": prewarm, "ms_per_step": step_ms,
         "ms_per_step_median": median_ms,
         "ms_per_step_min_max": [per_step_ms[0], per_step_ms[-1]],
+        # the first timed step starts on an idle device right behind the barrier + synchronize: nothing of it overlaps a
+        # previous step's tail, so it carries the host's whole enqueue time on top of the steady-state step
+        "ms_first_step": step_trace[0],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, "
                                f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on"

@@ -81,7 +81,7 @@ typedef struct GsrSegmentsC {
 #define GSR_SEG_TOTAL_WORDS 272
 #define GSR_TILE_ORDER_WORDS(num_tiles) (8 * 32 * (((num_tiles) + 7) / 8))
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 25) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 26) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -223,6 +223,16 @@ int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t 
                    const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out,
                    const uint32_t* M_dev /* NULL, or the device word with the visible count when M is a capacity: ranks at
                                             or beyond it get count 0 */, void* stream);
+/* gsr_tile_count followed by the exclusive scan of the counts in TWO launches instead of three (the count pass leaves
+ * per-block totals in the workspace, the scan pass adds them up itself): offsets_out [M], total_dev = the pair count O,
+ * overflow_flag raised when O reaches 2^31 (as gsr_exclusive_scan_u32_checked does).  M <= GSR_TILE_COUNT_OFFSETS_MAX
+ * (beyond that the totals in front of a block are too many to add up per block: use gsr_tile_count + the scan). */
+#define GSR_TILE_COUNT_OFFSETS_MAX 4194304
+size_t gsr_tile_count_offsets_workspace_bytes(int64_t M);
+int gsr_tile_count_offsets(const float* rows, const uint32_t* order, int64_t M, int32_t W, int32_t H,
+                           const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out,
+                           const uint32_t* M_dev, uint32_t* offsets_out, uint32_t* total_dev, uint32_t* overflow_flag,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* offsets = exclusive scan of count.  Instance i of rank k gets keys[offsets[k]+i] = tile id and
  * inst2splat[...] = order[k] | (half mask << 30): instances are emitted rank-major (already depth-sorted), the value they
  * carry is the splat id the composite kernels fetch the row by.

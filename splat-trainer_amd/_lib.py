@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -107,6 +107,8 @@ PROTOTYPES = {
                                             _p, _p, _i32, _p, _p, _p, _p, _p]),
     "gsr_pack_rows": (C.c_int, [_p, _p, _p, _i64, _i32, _pp, _p, _p, _p]),
     "gsr_tile_count": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p, _p]),
+    "gsr_tile_count_offsets_workspace_bytes": (_sz, [_i64]),
+    "gsr_tile_count_offsets": (C.c_int, [_p, _p, _i64, _i32, _i32, _pp, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gsr_tile_emit": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _pp, _p, _p, _i64, _p, _p]),
     "gsr_tile_ranges": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "gsr_segment_thresholds": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _p, _p]),

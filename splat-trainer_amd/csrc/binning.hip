@@ -56,20 +56,10 @@ __device__ __forceinline__ uint32_t hits_of_large_extent(float u, float v, float
   return n;
 }
 
-// Thread k = depth rank k.  The only crossing of the depth-order permutation on the forward side: ONE gather of the
-// first half of the splat's packed 64-byte row (geometry.hip: project_sh_fwd_kernel / pack_rows_kernel); the composite
-// kernels later fetch the rows by splat id through the scalar cache, so no depth-ordered copy of the records exists.
-__global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict__ rows,
-                                                         const uint32_t* __restrict__ order, int64_t M, int tiles_x,
-                                                         int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ count,
-                                                         TileHits* __restrict__ hits,
-                                                         const uint32_t* __restrict__ M_dev) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= M) return;
-  if (M_dev && k >= (int64_t)*M_dev) {        // M is a capacity: the visible count is still on the device
-    count[k] = 0u;                            // the scan over the capacity then needs no count of its own
-    return;
-  }
+// One depth rank's tile count and hit record (see TileHits).
+__device__ __forceinline__ uint32_t tile_count_one(const float* __restrict__ rows, const uint32_t* __restrict__ order,
+                                                   int64_t k, int tiles_x, int tiles_y, const GsrRasterParams& rp,
+                                                   TileHits* __restrict__ hits) {
   const int64_t s = order[k];
   const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * s);
   const float4 r0 = r[0];
@@ -98,9 +88,90 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict
       n = hits_of_large_extent(uv.x, uv.y, ab.x, ab.y, co.x, e, nullptr, nullptr, 0u, 0u, 0u, tiles_x);
     }
   }
-  count[k] = n;
   *reinterpret_cast<uint4*>(hits + k) = make_uint4(h.origin, h.shape, h.lo, h.hi);
+  return n;
 }
+
+// Thread k = depth rank k.  The only crossing of the depth-order permutation on the forward side: ONE gather of the
+// first half of the splat's packed 64-byte row (geometry.hip: project_sh_fwd_kernel / pack_rows_kernel); the composite
+// kernels later fetch the rows by splat id through the scalar cache, so no depth-ordered copy of the records exists.
+__global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict__ rows,
+                                                         const uint32_t* __restrict__ order, int64_t M, int tiles_x,
+                                                         int tiles_y, GsrRasterParams rp, uint32_t* __restrict__ count,
+                                                         TileHits* __restrict__ hits,
+                                                         const uint32_t* __restrict__ M_dev,
+                                                         uint32_t* __restrict__ block_sums) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (block_sums) {
+    // also leaves the block's total for offsets_from_sums_kernel (the scan's reduce pass, folded in here)
+    __shared__ uint32_t s_wave[4];
+    uint32_t n = 0u;
+    if (k < M) {
+      if (!(M_dev && k >= (int64_t)*M_dev)) n = tile_count_one(rows, order, k, tiles_x, tiles_y, rp, hits);
+      count[k] = n;
+    }
+    n = gsr_wave_sum_u32(n);
+    if (gsr_lane() == 0) s_wave[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
+    return;
+  }
+  if (k >= M) return;
+  if (M_dev && k >= (int64_t)*M_dev) {        // M is a capacity: the visible count is still on the device
+    count[k] = 0u;                            // the scan over the capacity then needs no count of its own
+    return;
+  }
+  count[k] = tile_count_one(rows, order, k, tiles_x, tiles_y, rp, hits);
+}
+
+// offsets = exclusive scan of count, from the per-256 totals tile_count_kernel left: a block scans 4096 counts and adds
+// up the totals in front of them itself (16 per block of this launch: a few thousand words at millions of splats).
+// Raises *overflow when the pair count reaches 2^31 (float shadow sums: range, not precision -- as prims.hip does).
+__global__ __launch_bounds__(256) void offsets_from_sums_kernel(const uint32_t* __restrict__ count, uint32_t n,
+                                                                const uint32_t* __restrict__ sums256,
+                                                                uint32_t* __restrict__ offsets,
+                                                                uint32_t* __restrict__ total_out,
+                                                                uint32_t* __restrict__ overflow) {
+  __shared__ uint32_t s_wave[4], s_before[4];
+  __shared__ float s_f[4];
+  const int lane = gsr_lane(), w = (int)(threadIdx.x >> 6);
+  const uint32_t base = blockIdx.x * 4096u + threadIdx.x * 16u;
+  uint32_t v[16], sum = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = (base + i < n) ? count[base + i] : 0u;
+    sum += v[i];
+  }
+  uint32_t before = 0u;
+  float fbefore = 0.f;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x * 16u; j += 256u) {
+    const uint32_t b = sums256[j];
+    before += b;
+    fbefore += (float)b;
+  }
+  const uint32_t incl = gsr_wave_scan_incl_u32(sum);
+  before = gsr_wave_sum_u32(before);
+  fbefore = gsr_wave_sum(fbefore + (float)sum);
+  if (lane == 63) s_wave[w] = incl;
+  if (lane == 0) { s_before[w] = before; s_f[w] = fbefore; }
+  __syncthreads();
+  uint32_t prefix = (s_before[0] + s_before[1]) + (s_before[2] + s_before[3]), total = 0u;
+  uint32_t in_block = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < w) in_block += s_wave[j];
+    total += s_wave[j];
+  }
+  if (threadIdx.x == 0 && (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]) >= 2147000000.f) *overflow = 1u;
+  uint32_t run = prefix + in_block + incl - sum;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (base + i < n) offsets[base + i] = run;
+    run += v[i];
+  }
+  if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = prefix + total;
+}
+
 
 // Instances are emitted rank-major (thread k = depth rank k writes the slots [offsets[k], offsets[k] + count[k])), so the
 // stream is already depth-sorted and a stable sort on the tile id finishes the per-tile lists; the VALUE an instance
@@ -303,7 +374,34 @@ int gsr_tile_count(const float* rows, const uint32_t* order, int64_t M, int32_t 
   const int tx = (W + 15) / 16, ty = (H + 15) / 16;
   if (tx > 0xFFFF || ty > 0xFFFF) return GSR_ERR_UNSUPPORTED;      // the hit records hold 16-bit tile coordinates
   tile_count_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rows, order, M, tx, ty, to_params(params_host), count_out,
-                                                         reinterpret_cast<TileHits*>(tile_hits_out), M_dev);
+                                                         reinterpret_cast<TileHits*>(tile_hits_out), M_dev, nullptr);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+size_t gsr_tile_count_offsets_workspace_bytes(int64_t M) {
+  return M > 0 ? (size_t)((M + 255) / 256) * sizeof(uint32_t) + 256 : 256;
+}
+
+int gsr_tile_count_offsets(const float* rows, const uint32_t* order, int64_t M, int32_t W, int32_t H,
+                           const GsrRasterParamsC* params_host, uint32_t* count_out, uint32_t* tile_hits_out,
+                           const uint32_t* M_dev, uint32_t* offsets_out, uint32_t* total_dev, uint32_t* overflow_flag,
+                           void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || M > GSR_TILE_COUNT_OFFSETS_MAX || !params_host || W <= 0 || H <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (params_host->tile_size != 16) return GSR_ERR_UNSUPPORTED;
+  if (!total_dev || !overflow_flag) return GSR_ERR_INVALID_ARGUMENT;
+  if (M == 0) { hipMemsetAsync(total_dev, 0, sizeof(uint32_t), stream); return GSR_OK; }
+  if (!rows || !order || !count_out || !tile_hits_out || !offsets_out) return GSR_ERR_INVALID_ARGUMENT;
+  if (!workspace || workspace_bytes < gsr_tile_count_offsets_workspace_bytes(M)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+  if (tx > 0xFFFF || ty > 0xFFFF) return GSR_ERR_UNSUPPORTED;
+  uint32_t* sums = reinterpret_cast<uint32_t*>(workspace);
+  tile_count_kernel<<<grid_for(M, 256), 256, 0, stream>>>(rows, order, M, tx, ty, to_params(params_host), count_out,
+                                                         reinterpret_cast<TileHits*>(tile_hits_out), M_dev, sums);
+  GSR_CHECK_LAUNCH();
+  offsets_from_sums_kernel<<<grid_for(M, 4096), 256, 0, stream>>>(count_out, (uint32_t)M, sums, offsets_out, total_dev,
+                                                                 overflow_flag);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

@@ -116,6 +116,8 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
   p->cull_ws_bytes = projected ? 0 : (int64_t)gsr_cull_workspace_bytes(N);
   p->sort_ws_bytes = (int64_t)gsr_sort_workspace_bytes(N);
   p->scan_ws_bytes = (int64_t)gsr_scan_workspace_bytes(N);
+  if (N <= GSR_TILE_COUNT_OFFSETS_MAX && (int64_t)gsr_tile_count_offsets_workspace_bytes(N) > p->scan_ws_bytes)
+    p->scan_ws_bytes = (int64_t)gsr_tile_count_offsets_workspace_bytes(N);
   p->tsort_ws_bytes = (int64_t)gsr_sort_workspace_bytes(cap);
   p->cull_ws = projected ? -1 : work.take(p->cull_ws_bytes);
   p->sort_ws = work.take(p->sort_ws_bytes);
@@ -206,9 +208,14 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
   uint32_t* count = at<uint32_t>(out, p->count);
   uint32_t* offsets = at<uint32_t>(out, p->offsets);
   uint32_t* hits = at<uint32_t>(work, p->tile_hits);
-  GSR_TRY(gsr_tile_count(rows, order, N, f->W, f->H, &f->params, count, hits, M_dev, stream_));
-  GSR_TRY(gsr_exclusive_scan_u32_checked(count, offsets, N, O_dev, counts + 2, at<uint8_t>(work, p->scan_ws),
-                                         (size_t)p->scan_ws_bytes, stream_));
+  if (N <= GSR_TILE_COUNT_OFFSETS_MAX) {
+    GSR_TRY(gsr_tile_count_offsets(rows, order, N, f->W, f->H, &f->params, count, hits, M_dev, offsets, O_dev, counts + 2,
+                                   at<uint8_t>(work, p->scan_ws), (size_t)p->scan_ws_bytes, stream_));
+  } else {
+    GSR_TRY(gsr_tile_count(rows, order, N, f->W, f->H, &f->params, count, hits, M_dev, stream_));
+    GSR_TRY(gsr_exclusive_scan_u32_checked(count, offsets, N, O_dev, counts + 2, at<uint8_t>(work, p->scan_ws),
+                                           (size_t)p->scan_ws_bytes, stream_));
+  }
   // [M, O, overflow] are final here: their copy to the host goes in NOW, in the middle of the chain, so that the host --
   // which needs them to shape the frame's tensors and goes on to enqueue the loss and the backward pass -- gets them
   // while the device still has the emit, the tile sort and the composite ahead of it

@@ -9,6 +9,7 @@ namespace {
 
 constexpr int CULL_ITEMS = 16;                     // points per lane
 constexpr int CULL_WAVE_SPAN = 64 * CULL_ITEMS;    // 1024 consecutive points per wave
+constexpr int64_t CULL_SELF_PREFIX_MAX_WAVES = 4096;    // up to 4.2 M points the write pass sums the wave counts itself
 
 // pass 1: each wave counts the in-view points of its 1024-point span (ballot + popcount)
 __global__ __launch_bounds__(256) void cull_count_kernel(const float* __restrict__ pos, int64_t N,
@@ -36,13 +37,24 @@ __global__ __launch_bounds__(256) void cull_write_kernel(const float* __restrict
                                                          const float* __restrict__ Tcw, const float* __restrict__ proj,
                                                          int W, int H, float near_p, float far_p, float margin,
                                                          const uint32_t* __restrict__ wave_offsets, int64_t num_waves,
-                                                         int64_t* __restrict__ indexes) {
+                                                         int64_t* __restrict__ indexes,
+                                                         uint32_t* __restrict__ count_dev) {
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wave >= num_waves) return;
   const int lane = gsr_lane();
   const GsrCam cam = gsr_load_cam(Tcw, proj);
   const int64_t base = wave * CULL_WAVE_SPAN;
-  uint32_t run = wave_offsets[wave];
+  uint32_t run;
+  if (count_dev) {
+    // wave_offsets holds the waves' RAW counts: every wave adds up its predecessors' itself (a few thousand words at
+    // millions of points -- cheaper than a scan launch in between) and the last one leaves the total
+    uint32_t before = 0u;
+    for (int64_t j = lane; j < wave; j += 64) before += wave_offsets[j];
+    run = gsr_wave_sum_u32(before);
+    if (wave == num_waves - 1 && lane == 0) *count_dev = run + wave_offsets[wave];
+  } else {
+    run = wave_offsets[wave];
+  }
 #pragma unroll 4
   for (int it = 0; it < CULL_ITEMS; ++it) {
     int64_t i = base + it * 64 + lane;
@@ -684,7 +696,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 25; }
+int gsr_abi_version(void) { return 26; }
 
 const char* gsr_error_string(int code) {
   switch (code) {
@@ -720,10 +732,13 @@ int gsr_frustum_cull(const float* position, int64_t N, const float* T_camera_wor
   cull_count_kernel<<<blocks, 256, 0, stream>>>(position, N, T_camera_world, projection, W, H, near_plane, far_plane,
                                                margin_px, wave_counts, nw);
   GSR_CHECK_LAUNCH();
-  int rc = gsr_exclusive_scan_u32(wave_counts, wave_counts, nw, count_dev, scan_ws, workspace_bytes - counts_bytes, stream_);
-  if (rc != GSR_OK) return rc;
+  const bool self_prefix = nw <= CULL_SELF_PREFIX_MAX_WAVES;
+  if (!self_prefix) {
+    int rc = gsr_exclusive_scan_u32(wave_counts, wave_counts, nw, count_dev, scan_ws, workspace_bytes - counts_bytes, stream_);
+    if (rc != GSR_OK) return rc;
+  }
   cull_write_kernel<<<blocks, 256, 0, stream>>>(position, N, T_camera_world, projection, W, H, near_plane, far_plane,
-                                               margin_px, wave_counts, nw, indexes_out);
+                                               margin_px, wave_counts, nw, indexes_out, self_prefix ? count_dev : nullptr);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

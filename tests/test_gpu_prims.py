@@ -208,3 +208,51 @@ def test_radix_sort_two_values(n, bits):
   assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
   assert np.array_equal(v.cpu().numpy().view(np.uint32), order.astype(np.uint32))
   assert np.array_equal(v2.cpu().numpy().view(np.uint32), vals2[order])
+
+
+@pytest.mark.parametrize("m,visible", [(1, None), (255, None), (4097, None), (70_001, None), (70_001, 50_000),
+                                       (1_000_000, 999_999)])
+def test_tile_count_with_offsets_equals_count_then_scan(m, visible):
+  """K4's count + offsets in two launches (the count pass leaves per-block totals, the scan pass adds them up itself)
+  against gsr_tile_count + gsr_exclusive_scan_u32_checked: counts, hit records, offsets and the total, bit for bit."""
+  lib = _lib.load()
+  gen = torch.Generator().manual_seed(m)
+  W, H = 1280, 720
+  rows = torch.zeros(m, 16)                                              # packed rows: u v A B | C opacity ...
+  sig = 0.5 + 20.0 * torch.rand(m, generator=gen) ** 3                     # a few wide splats among many small ones
+  rows[:, 0] = torch.rand(m, generator=gen) * (W + 100) - 50
+  rows[:, 1] = torch.rand(m, generator=gen) * (H + 100) - 50
+  rows[:, 2] = 1.0 / sig ** 2
+  rows[:, 4] = 1.0 / (sig * (0.5 + torch.rand(m, generator=gen))) ** 2
+  rows[:, 5] = 0.05 + 0.9 * torch.rand(m, generator=gen)
+  rows = rows.cuda()
+  order = torch.randperm(m, generator=gen).to(torch.int32).cuda()
+  params = _lib.GsrRasterParamsC(1.0 / 255.0, 0.99, 1e-4, 9.0, 0.3, 0, 16, 48.0)
+  m_dev = torch.tensor([visible], dtype=torch.int32, device="cuda") if visible is not None else None
+  mp = _ptr(m_dev) if m_dev is not None else None
+  outs = []
+  for fused in (True, False):
+    count = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+    hits = torch.zeros(m, 4, dtype=torch.int32, device="cuda")
+    offsets = torch.full((m,), -1, dtype=torch.int32, device="cuda")
+    total = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if fused:
+      nbytes = lib.gsr_tile_count_offsets_workspace_bytes(m)
+      ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+      _lib.check(lib.gsr_tile_count_offsets(_ptr(rows), _ptr(order), m, W, H, C.byref(params), _ptr(count), _ptr(hits), mp,
+                                            _ptr(offsets), _ptr(total), _ptr(flag), _ptr(ws), nbytes, _stream()),
+                 "tile_count_offsets")
+    else:
+      _lib.check(lib.gsr_tile_count(_ptr(rows), _ptr(order), m, W, H, C.byref(params), _ptr(count), _ptr(hits), mp,
+                                    _stream()), "tile_count")
+      nbytes = lib.gsr_scan_workspace_bytes(m)
+      ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+      _lib.check(lib.gsr_exclusive_scan_u32_checked(_ptr(count), _ptr(offsets), m, _ptr(total), _ptr(flag), _ptr(ws),
+                                                    nbytes, _stream()), "scan")
+    assert flag.item() == 0
+    live = m if visible is None else visible
+    outs.append((count.cpu(), offsets.cpu(), total.item(), hits[:live].cpu()))
+  (c1, o1, t1, h1), (c2, o2, t2, h2) = outs
+  assert torch.equal(c1, c2) and torch.equal(o1, o2) and t1 == t2 and torch.equal(h1, h2)
+  assert t1 == int(c1.to(torch.int64).sum()) and (m < 1000 or t1 > m // 2)

@@ -843,54 +843,69 @@ __global__ __launch_bounds__(256) void segment_plan_kernel(const uint32_t* __res
                                                            uint32_t* __restrict__ seg_total,
                                                            uint32_t* __restrict__ tile_order) {
   const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (t >= num_tiles) return;
-  uint32_t seg_pairs, heavy_min;
-  const int64_t O_now = O_dev ? (int64_t)*O_dev : O;
-  segment_thresholds(seg_cfg, heavy_cfg, O_now, num_tiles, needs_grad, &seg_pairs, &heavy_min);
-  const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
-  // a heavy tile's segments are also FORWARD work units (alpha-product pass + a prologue over the preceding segments):
-  // about 256 pairs each and at most ~128 per tile; a long tile's segments are only checkpoints: seg_pairs each
-  bool heavy = len > heavy_min;
-  const uint32_t seg_heavy = max(seg_pairs, min(256u, (heavy_min / 2u) & ~3u));
-  const uint32_t seg_t = heavy ? max(seg_heavy, (((len + 127u) / 128u) + 3u) & ~3u) : seg_pairs;
-  uint32_t n = len > seg_pairs ? (len + seg_t - 1) / seg_t : 0u;
-  uint32_t at = 0u;
-  if (n) {
-    at = atomicAdd(seg_total, n);
-    if (at + n > capacity) {                       // cannot happen with the host's bound; stay in range regardless:
-      for (uint32_t j = at; j < capacity; ++j) {   // the tile stays unsegmented and its reserved slots become empty segments
-        uint32_t* d = seg_desc + 4 * (size_t)j;
-        d[0] = (uint32_t)t; d[1] = a; d[2] = a; d[3] = 0u;
+  // K6's launch order (see GSR_TILE_CLASSES): the block counts its tiles per (band, class) in LDS first, so that the
+  // global counters take one atomic per non-empty (band, class) of the block instead of one per tile
+  __shared__ uint32_t s_count[8 * GSR_TILE_CLASSES], s_base[8 * GSR_TILE_CLASSES];
+  static_assert(8 * GSR_TILE_CLASSES == 256, "one LDS counter per thread of the block");
+  s_count[threadIdx.x] = 0u;
+  __syncthreads();
+  bool filed = false;
+  uint32_t key = 0u, local = 0u;
+  if (t < num_tiles) {
+    uint32_t seg_pairs, heavy_min;
+    const int64_t O_now = O_dev ? (int64_t)*O_dev : O;
+    segment_thresholds(seg_cfg, heavy_cfg, O_now, num_tiles, needs_grad, &seg_pairs, &heavy_min);
+    const uint32_t a = tile_range[2 * t], len = tile_range[2 * t + 1] - a;
+    // a heavy tile's segments are also FORWARD work units (alpha-product pass + a prologue over the preceding segments):
+    // about 256 pairs each and at most ~128 per tile; a long tile's segments are only checkpoints: seg_pairs each
+    bool heavy = len > heavy_min;
+    const uint32_t seg_heavy = max(seg_pairs, min(256u, (heavy_min / 2u) & ~3u));
+    const uint32_t seg_t = heavy ? max(seg_heavy, (((len + 127u) / 128u) + 3u) & ~3u) : seg_pairs;
+    uint32_t n = len > seg_pairs ? (len + seg_t - 1) / seg_t : 0u;
+    uint32_t at = 0u;
+    if (n) {
+      at = atomicAdd(seg_total, n);
+      if (at + n > capacity) {                       // cannot happen with the host's bound; stay in range regardless:
+        for (uint32_t j = at; j < capacity; ++j) {   // the tile stays unsegmented and its reserved slots become empty segments
+          uint32_t* d = seg_desc + 4 * (size_t)j;
+          d[0] = (uint32_t)t; d[1] = a; d[2] = a; d[3] = 0u;
+        }
+        n = 0u;
       }
-      n = 0u;
+    }
+    // the segments of heavy tiles are also listed compactly (behind the tile table): the forward passes that only
+    // concern them launch one block per entry of that list instead of one per segment of the frame
+    if (n && heavy) {
+      const uint32_t hat = atomicAdd(seg_total + 1, n);
+      if (hat + n <= heavy_capacity) {
+        uint32_t* list = tile_seg + 2 * (size_t)num_tiles;
+        for (uint32_t j = 0; j < n; ++j) list[hat + j] = at + j;
+      } else {                  // cannot happen with the host's bound; stay in range regardless: the one-wave walk with
+        heavy = false;          // checkpoints takes the tile and the list's tail holds "no segment"
+        uint32_t* list = tile_seg + 2 * (size_t)num_tiles;
+        for (uint32_t j = hat; j < heavy_capacity; ++j) list[j] = 0xFFFFFFFFu;
+      }
+    }
+    tile_seg[2 * t] = at;
+    tile_seg[2 * t + 1] = n | ((n && heavy) ? GSR_SEG_HEAVY : 0u);
+    if (tile_order && !(n && heavy)) {               // (heavy tiles are composited by the segment passes)
+      const uint32_t mean = (uint32_t)max((int64_t)1, O_now / num_tiles);
+      const uint32_t cls = min((uint32_t)(GSR_TILE_CLASSES - 1), len * 8u / mean);
+      key = (uint32_t)gsr_tile_band(t, num_tiles) * GSR_TILE_CLASSES + cls;
+      local = atomicAdd(&s_count[key], 1u);
+      filed = true;
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+      uint32_t* d = seg_desc + 4 * (size_t)(at + j);
+      d[0] = (uint32_t)t; d[1] = a + j * seg_t; d[2] = min(a + (j + 1) * seg_t, a + len); d[3] = j;
     }
   }
-  // the segments of heavy tiles are also listed compactly (behind the tile table): the forward passes that only
-  // concern them launch one block per entry of that list instead of one per segment of the frame
-  if (n && heavy) {
-    const uint32_t hat = atomicAdd(seg_total + 1, n);
-    if (hat + n <= heavy_capacity) {
-      uint32_t* list = tile_seg + 2 * (size_t)num_tiles;
-      for (uint32_t j = 0; j < n; ++j) list[hat + j] = at + j;
-    } else {                  // cannot happen with the host's bound; stay in range regardless: the one-wave walk with
-      heavy = false;          // checkpoints takes the tile and the list's tail holds "no segment"
-      uint32_t* list = tile_seg + 2 * (size_t)num_tiles;
-      for (uint32_t j = hat; j < heavy_capacity; ++j) list[j] = 0xFFFFFFFFu;
-    }
-  }
-  tile_seg[2 * t] = at;
-  tile_seg[2 * t + 1] = n | ((n && heavy) ? GSR_SEG_HEAVY : 0u);
-  if (tile_order && !(n && heavy)) {               // K6's queues (heavy tiles are composited by the segment passes)
-    const uint32_t mean = (uint32_t)max((int64_t)1, O_now / num_tiles);
-    const uint32_t cls = min((uint32_t)(GSR_TILE_CLASSES - 1), len * 8u / mean);
-    const uint32_t band = (uint32_t)gsr_tile_band(t, num_tiles);
-    const uint32_t slot = atomicAdd(seg_total + GSR_SEG_CLASS_COUNT(band) + cls, 1u);
-    tile_order[((size_t)band * GSR_TILE_CLASSES + cls) * (size_t)gsr_tile_band_stride(num_tiles) + slot] = (uint32_t)t;
-  }
-  for (uint32_t j = 0; j < n; ++j) {
-    uint32_t* d = seg_desc + 4 * (size_t)(at + j);
-    d[0] = (uint32_t)t; d[1] = a + j * seg_t; d[2] = min(a + (j + 1) * seg_t, a + len); d[3] = j;
-  }
+  __syncthreads();
+  if (s_count[threadIdx.x])                          // thread i owns (band, class) i: GSR_SEG_CLASS_COUNT(band) + class = 16 + i
+    s_base[threadIdx.x] = atomicAdd(seg_total + GSR_SEG_CLASS_COUNT(0) + threadIdx.x, s_count[threadIdx.x]);
+  __syncthreads();
+  if (filed)
+    tile_order[(size_t)key * (size_t)gsr_tile_band_stride(num_tiles) + s_base[key] + local] = (uint32_t)t;
 }
 
 inline SegDev to_segdev(const GsrSegmentsC* sg) {

@@ -299,7 +299,8 @@ def main():
   for m in marks:
     m.record()
   sync()
-  renderer.KERNEL_TIMER = timer
+  if os.environ.get("BENCH_NO_KERNEL_TIMER") != "1":      # (diagnostic: the cost of the roofline leg's events on a host-bound step)
+    renderer.KERNEL_TIMER = timer
   t0 = time.perf_counter()
   marks[0].record()
   for i in range(args.steps):

@@ -81,7 +81,10 @@ typedef struct GsrSegmentsC {
 #define GSR_SEG_TOTAL_WORDS 272
 #define GSR_TILE_ORDER_WORDS(num_tiles) (8 * 32 * (((num_tiles) + 7) / 8))
 
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 26) */
+/* sizeof of the ABI's structs as the library was compiled: 0 GsrRasterParamsC, 1 GsrSegmentsC, 2 GsrFrameC,
+ * 3 GsrFramePlanC, 4 GsrFrameResultC, 5 GsrFrameBackwardC (-1 otherwise) -- for a binding to check its own layout. */
+int64_t gsr_struct_bytes(int32_t which);
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 27) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -390,6 +393,40 @@ int gsr_frame_plan(const GsrFrameC* frame_host, GsrFramePlanC* plan_out_host);
 int gsr_frame_forward(const GsrFrameC* frame_host, const GsrFramePlanC* plan_host, void* out_arena, void* work_arena,
                       GsrFrameResultC* result_out_host, uint32_t* counts_host, void* event_counts, void* event_k6_begin,
                       void* event_k6_end, void* stream);
+
+/* The backward half of the same frame behind one call (loss.backward() through the node of scene.render,
+ * splat_trainer/trainer/trainer.py:512): K7 -> gsr_reduce_gradients -> (gsr_inverse_map) -> gsr_project_backward_rows ->
+ * gsr_sh_backward(_dense), with the arguments those entry points take.  All buffers are the caller's. */
+typedef struct GsrFrameBackwardC {
+  /* scene and camera of the forward call */
+  const float* position; const float* log_scaling; const float* rotation_xyzw; const float* alpha_logit;
+  const float* sh_features;       /* [N,3,K]; only read when sh_mode != 0 */
+  int64_t N; int32_t K; int32_t W, H, C;
+  const float* T_camera_world; const float* projection; const float* camera_pos;
+  GsrRasterParamsC params;
+  /* what the forward pass left (gsr_frame_forward's out arena) */
+  int64_t M, O;
+  const int64_t* indexes; const float* rows; const uint32_t* order; const uint32_t* count; const uint32_t* offsets;
+  const uint32_t* sorted_splat; const uint32_t* sorted_inst; const float* pair_vis; const float* vis_partial;
+  const uint32_t* tile_range; const float* final_T; const int32_t* last; const float* image;
+  const float* jacobian;          /* [M,9] or NULL */
+  const GsrSegmentsC* segments;   /* host pointer, or NULL */
+  /* incoming gradients: d_image [H,W,C] (NULL: nothing reached the image), and what reached gaussians2d / depth */
+  const float* d_image; const float* d_gaussians2d; const float* d_depth;
+  /* scratch */
+  float* partial;                 /* [O, GSR_PARTIAL_FLOATS] */
+  float* grad_rows;               /* [M, GSR_ROW_FLOATS] */
+  int32_t* inverse;               /* [N]; needed when M < N and (mode == 2 or sh_mode == 1) */
+  float* d_colors;                /* [M,3]; needed when sh_mode != 0 (may be given otherwise: the colour gradient) */
+  /* outputs: geometry gradients [N,*] with gsr_project_backward_rows' mode; the SH coefficient gradient [N,3,K] with
+   * sh_mode 0: none, 1: every row overwritten (gsr_sh_backward_dense), 2: rows of `indexes` accumulated; the per-point
+   * outputs [M] (each may be NULL) */
+  float* d_position; float* d_log_scaling; float* d_rotation; float* d_alpha_logit; int32_t mode;
+  float* d_sh; int32_t sh_mode;
+  float* prune_cost; float* split_score; float* visibility;
+} GsrFrameBackwardC;
+/* event_k7_begin / event_k7_end: hipEvent_t recorded around the composite backward launch, or NULL. */
+int gsr_frame_backward(const GsrFrameBackwardC* backward_host, void* event_k7_begin, void* event_k7_end, void* stream);
 
 /* ---- loss stage next to the path: fused SSIM, replaces the CUDA-only fused_ssim package
  *      the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462; trainer/evaluation.py:7,42) ------------ */

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -52,6 +52,22 @@ FRAME_PLAN_FIELDS = ("out_bytes", "work_bytes", "zero_begin", "zero_bytes", "pru
 
 class GsrFramePlanC(C.Structure):
   _fields_ = [(name, C.c_int64) for name in FRAME_PLAN_FIELDS]
+
+
+class GsrFrameBackwardC(C.Structure):
+  _fields_ = [("position", C.c_void_p), ("log_scaling", C.c_void_p), ("rotation_xyzw", C.c_void_p),
+              ("alpha_logit", C.c_void_p), ("sh_features", C.c_void_p), ("N", C.c_int64), ("K", C.c_int32),
+              ("W", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("T_camera_world", C.c_void_p),
+              ("projection", C.c_void_p), ("camera_pos", C.c_void_p), ("params", GsrRasterParamsC), ("M", C.c_int64),
+              ("O", C.c_int64), ("indexes", C.c_void_p), ("rows", C.c_void_p), ("order", C.c_void_p),
+              ("count", C.c_void_p), ("offsets", C.c_void_p), ("sorted_splat", C.c_void_p), ("sorted_inst", C.c_void_p),
+              ("pair_vis", C.c_void_p), ("vis_partial", C.c_void_p), ("tile_range", C.c_void_p), ("final_T", C.c_void_p),
+              ("last", C.c_void_p), ("image", C.c_void_p), ("jacobian", C.c_void_p), ("segments", C.c_void_p),
+              ("d_image", C.c_void_p), ("d_gaussians2d", C.c_void_p), ("d_depth", C.c_void_p), ("partial", C.c_void_p),
+              ("grad_rows", C.c_void_p), ("inverse", C.c_void_p), ("d_colors", C.c_void_p), ("d_position", C.c_void_p),
+              ("d_log_scaling", C.c_void_p), ("d_rotation", C.c_void_p), ("d_alpha_logit", C.c_void_p),
+              ("mode", C.c_int32), ("d_sh", C.c_void_p), ("sh_mode", C.c_int32), ("prune_cost", C.c_void_p),
+              ("split_score", C.c_void_p), ("visibility", C.c_void_p)]
 
 
 class GsrFrameResultC(C.Structure):
@@ -135,6 +151,8 @@ PROTOTYPES = {
     "gsr_dp_replay": (C.c_int, [_p, _i64, _p, _i32, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_frame_plan": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC)]),
+    "gsr_struct_bytes": (_i64, [_i32]),
+    "gsr_frame_backward": (C.c_int, [C.POINTER(GsrFrameBackwardC), _p, _p, _p]),
     "gsr_frame_forward": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC), _p, _p, C.POINTER(GsrFrameResultC), _p,
                                     _p, _p, _p, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
@@ -146,10 +164,10 @@ _lib = None
 _lock = threading.Lock()
 
 
-def current_stream_ptr() -> C.c_void_p:
+def current_stream_ptr() -> int:
   """hipStream_t of torch's current stream on the current device.  (torch.cuda.current_stream() costs ~13 us per call
   on this stack -- device-availability probing -- and a step makes a dozen launches; the raw getter costs well under 1 us.)"""
-  return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+  return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())    # (0 = the null stream; ctypes passes the int)
 
 
 def current_stream() -> "torch.cuda.Stream":

@@ -285,4 +285,68 @@ int gsr_frame_forward(const GsrFrameC* f, const GsrFramePlanC* p, void* out, voi
   return GSR_OK;
 }
 
+// sizeof of the ABI's structs as this library was compiled (0 GsrRasterParamsC, 1 GsrSegmentsC, 2 GsrFrameC, 3 GsrFramePlanC,
+// 4 GsrFrameResultC, 5 GsrFrameBackwardC; -1 otherwise): lets a binding check its own layout before the first call.
+int64_t gsr_struct_bytes(int32_t which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(GsrRasterParamsC);
+    case 1: return (int64_t)sizeof(GsrSegmentsC);
+    case 2: return (int64_t)sizeof(GsrFrameC);
+    case 3: return (int64_t)sizeof(GsrFramePlanC);
+    case 4: return (int64_t)sizeof(GsrFrameResultC);
+    case 5: return (int64_t)sizeof(GsrFrameBackwardC);
+    default: return -1;
+  }
+}
+
+// The backward half behind one call: K7 -> per-splat reduction -> (inverse map) -> geometry sweep -> SH coefficient
+// gradient, the launches renderer._FrameFn.backward used to make one ctypes call at a time.
+int gsr_frame_backward(const GsrFrameBackwardC* b, void* event_k7_begin, void* event_k7_end, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!b || b->N < 0 || b->M < 0 || b->M > b->N || b->O < 0 || b->mode < 0 || b->mode > 2 || b->sh_mode < 0 ||
+      b->sh_mode > 2)
+    return GSR_ERR_INVALID_ARGUMENT;
+  const int64_t M = b->M, N = b->N;
+  if (M > 0 && (!b->grad_rows || !b->rows || !b->indexes)) return GSR_ERR_INVALID_ARGUMENT;
+  if (b->sh_mode && (!b->d_sh || !b->sh_features || !b->camera_pos || (M > 0 && !b->d_colors))) return GSR_ERR_INVALID_ARGUMENT;
+  const bool needs_inverse = M < N && (b->mode == 2 || b->sh_mode == 1);
+  if (needs_inverse && !b->inverse) return GSR_ERR_INVALID_ARGUMENT;
+#define GSR_TRY(call)                 \
+  do {                                \
+    const int rc_ = (call);           \
+    if (rc_ < 0) return rc_;          \
+  } while (0)
+  const bool live = M > 0 && b->O > 0 && b->d_image != nullptr;
+  if (live) {
+    if (!b->partial || !b->vis_partial) return GSR_ERR_INVALID_ARGUMENT;
+    if (event_k7_begin && hipEventRecord(reinterpret_cast<hipEvent_t>(event_k7_begin), stream) != hipSuccess)
+      return GSR_ERR_LAUNCH_FAILED;
+    GSR_TRY(gsr_composite_backward(b->rows, b->sorted_splat, b->sorted_inst, b->pair_vis, b->tile_range, b->W, b->H, b->C,
+                                   &b->params, b->final_T, b->last, b->d_image, b->image, b->partial, b->segments, stream_));
+    if (event_k7_end && hipEventRecord(reinterpret_cast<hipEvent_t>(event_k7_end), stream) != hipSuccess)
+      return GSR_ERR_LAUNCH_FAILED;
+    GSR_TRY(gsr_reduce_gradients(b->partial, b->vis_partial, b->offsets, b->count, b->order, M, b->grad_rows, stream_));
+  } else if (M > 0) {
+    if (hipMemsetAsync(b->grad_rows, 0, (size_t)M * GSR_ROW_FLOATS * sizeof(float), stream) != hipSuccess)
+      return GSR_ERR_LAUNCH_FAILED;
+  }
+  if (needs_inverse) GSR_TRY(gsr_inverse_map(b->indexes, M, N, b->inverse, stream_));
+  if (M > 0 || b->mode == 2)
+    GSR_TRY(gsr_project_backward_rows(b->position, b->log_scaling, b->rotation_xyzw, b->alpha_logit, b->indexes, M,
+                                      b->mode == 2 ? b->inverse : nullptr, N, b->T_camera_world, b->projection, &b->params,
+                                      b->rows, b->grad_rows, b->d_gaussians2d, b->d_depth, b->jacobian, b->d_position,
+                                      b->d_log_scaling, b->d_rotation, b->d_alpha_logit, b->mode, b->d_colors,
+                                      live ? b->prune_cost : nullptr, live ? b->split_score : nullptr,
+                                      live ? b->visibility : nullptr, stream_));
+  if (b->sh_mode == 1) {
+    GSR_TRY(gsr_sh_backward_dense(b->d_colors, b->sh_features, b->position, b->inverse, M, N, b->K, b->camera_pos, nullptr,
+                                  b->d_sh, nullptr, stream_));
+  } else if (b->sh_mode == 2 && M > 0) {
+    GSR_TRY(gsr_sh_backward(b->d_colors, b->sh_features, b->position, b->indexes, M, b->K, b->camera_pos, nullptr, b->d_sh,
+                            nullptr, 1, stream_));
+  }
+#undef GSR_TRY
+  return GSR_OK;
+}
+
 }  // extern "C"

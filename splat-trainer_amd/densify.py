@@ -23,7 +23,7 @@ _stream = _lib.current_stream_ptr
 
 
 def _p(t: Optional[torch.Tensor]):
-  return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+  return None if t is None or t.numel() == 0 else t.data_ptr()     # plain int: the prototypes declare c_void_p
 
 
 def select_n(values: torch.Tensor, n: int, descending: bool = False) -> torch.Tensor:

@@ -18,7 +18,7 @@ from . import _lib
 
 
 def _ptr(t):
-  return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+  return None if t is None or t.numel() == 0 else t.data_ptr()     # plain int: the prototypes declare c_void_p
 
 
 _stream = _lib.current_stream_ptr

@@ -54,7 +54,7 @@ class VisibilityAwareLaProp(VisibilityOptimizer, SparseLaProp):
 
 
 def _ptr(t: Optional[torch.Tensor]):
-  return None if t is None else C.c_void_p(t.data_ptr())
+  return None if t is None else t.data_ptr()     # plain int: the prototypes declare c_void_p
 
 
 def point_basis_rows(log_scaling: torch.Tensor, rotation: torch.Tensor, indexes: Optional[torch.Tensor] = None,

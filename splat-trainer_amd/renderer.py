@@ -59,11 +59,20 @@ class KernelTimer:
   def begin(self, name: str):
     self._open[name] = self._event()
 
+  def _materialized(self):
+    """An event whose native handle exists (pool events were recorded once when they were reserved)."""
+    if self._pool:
+      return self._pool.pop()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(_lib.current_stream())
+    return e
+
   def pair(self, name: str):
-    """Two events for a native caller to record around a launch itself (frame driver): returns their raw handles."""
-    a, b = self._event(), self._event()
+    """Two events for a native caller to record around a launch itself (frame driver): returns their raw handles.
+    (Not recorded here: on a host-bound frame every torch-side record is a few microseconds of the step.)"""
+    a, b = self._materialized(), self._materialized()
     self.events.setdefault(name, []).append((a, b))
-    return C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)
+    return a.cuda_event, b.cuda_event
 
   def end(self, name: str):
     self.events.setdefault(name, []).append((self._open.pop(name), self._event()))
@@ -87,10 +96,10 @@ def _ptr(t):
   if t is None:
     return None
   if isinstance(t, int):
-    return C.c_void_p(t) if t else None
+    return t or None
   if t.numel() == 0:
     return None
-  return C.c_void_p(t.data_ptr())
+  return t.data_ptr()          # (the prototypes declare c_void_p: ctypes takes the plain int, no wrapper object per argument)
 
 
 _stream = _lib.current_stream_ptr
@@ -646,45 +655,47 @@ class _FrameFn(torch.autograd.Function):
       mode = 2 if dense else 0
     # the SH coefficient gradient: to the factor collector (data-parallel), into caller-owned buffers, or returned
     want_sh = collector is not None or sh_out is not None or ctx.needs_input_grad[4]
-    d_sh = None
-    inv = None
-    if M < N and N > 0 and dense:
-      inv = torch.empty(N, dtype=torch.int32, device=dev)        # scene row -> visible rank (shared with the SH backward)
-      _lib.check(lib.gsr_inverse_map(_ptr(indexes), M, N, _ptr(inv), _stream()), "gsr_inverse_map")
-    if M > 0 or mode == 2:
-      live = M > 0 and st.O > 0 and d_image is not None
-      grows = _composite_backward_rows(st, d_image, dev) if M > 0 else None
-      dg = _f32c(d_g2d) if d_g2d is not None else None
-      dd = _f32c(d_depth).reshape(-1) if d_depth is not None else None
-      dcol = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_sh else None
-      _lib.check(lib.gsr_project_backward_rows(_ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(indexes), M,
-                                               _ptr(inv) if mode == 2 else None, N, _ptr(T), _ptr(proj),
-                                               C.byref(st.params), _ptr(st.rows), _ptr(grows), _ptr(dg), _ptr(dd),
-                                               _ptr(ctx.jac),
-                                               _ptr(d_pos), _ptr(d_ls), _ptr(d_rot), _ptr(d_al), mode, _ptr(dcol),
-                                               _ptr(st.prune_cost) if live else None,
-                                               _ptr(st.split_score) if live else None, _ptr(_vis_out(st, live)),
-                                               _stream()), "gsr_project_backward_rows")
-    else:
-      dcol = torch.zeros(0, 3, dtype=torch.float32, device=dev) if want_sh else None
-    if collector is not None:              # data-parallel factor exchange: keep only the colour gradient
-      collector.items.append((indexes, dcol, cam))
-    elif want_sh:
+    d_sh, owner, sh_mode = None, None, 0
+    if collector is None and want_sh:
       owner = sh_out[2] if (sh_out is not None and len(sh_out) > 2) else None
       overwrite = sh_out is None or (owner is not None and owner.feature_uninitialized)
       d_sh = sh_out[0] if sh_out is not None else torch.empty(N, 3, K, dtype=torch.float32, device=dev)
       if overwrite and dense:
-        # every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no read-modify-write
-        _lib.check(lib.gsr_sh_backward_dense(_ptr(dcol), _ptr(sh), _ptr(pos), _ptr(inv), M, N, K, _ptr(cam), None,
-                                             _ptr(d_sh), None, _stream()), "gsr_sh_backward_dense")
+        sh_mode = 1              # every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no RMW
       else:
+        sh_mode = 2              # rows of `indexes` accumulate
         if overwrite:
           d_sh.zero_()
-        if M > 0:
-          _lib.check(lib.gsr_sh_backward(_ptr(dcol), _ptr(sh), _ptr(pos), _ptr(indexes), M, K, _ptr(cam), None,
-                                         _ptr(d_sh), None, 1, _stream()), "gsr_sh_backward")
-      if owner is not None:
-        owner.feature_uninitialized = False
+    if N > 0:
+      # the backward half of the frame behind ONE native call (csrc/frame.hip: gsr_frame_backward):
+      # K7 -> packed gradient rows -> (scene row -> visible rank map) -> geometry sweep -> SH coefficient gradient
+      live = M > 0 and st.O > 0 and d_image is not None
+      if live and st.vis_partial is None:
+        raise _lib.GsplatHipError("backward called on a rendering made without gradient state")
+      inv = torch.empty(N, dtype=torch.int32, device=dev) if (M < N and dense) else None
+      partial = torch.empty(st.O, PARTIAL_FLOATS, dtype=torch.float32, device=dev) if live else None
+      grows = torch.empty(M, ROW_FLOATS, dtype=torch.float32, device=dev) if M > 0 else None
+      dcol = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_sh else None
+      dimg = _f32c(d_image) if live else None
+      dg = _f32c(d_g2d) if d_g2d is not None else None
+      dd = _f32c(d_depth).reshape(-1) if d_depth is not None else None
+      timer = KERNEL_TIMER
+      ev = timer.pair("composite_backward") if (timer is not None and live) else (None, None)
+      seg = C.addressof(st.segments) if st.segments is not None else None
+      args = _lib.GsrFrameBackwardC(
+          _ptr(pos), _ptr(ls), _ptr(rot), _ptr(al), _ptr(sh), N, K, st.W, st.H, st.C, _ptr(T), _ptr(proj), _ptr(cam),
+          st.params, M, st.O, _ptr(indexes), _ptr(st.rows), _ptr(st.order), _ptr(st.count), _ptr(st.offsets),
+          _ptr(st.sorted_splat), _ptr(st.sorted_inst), _ptr(st.pair_vis), _ptr(st.vis_partial), _ptr(st.tile_range),
+          _ptr(st.final_T), _ptr(st.last), _ptr(st.image), _ptr(ctx.jac), seg, _ptr(dimg), _ptr(dg), _ptr(dd),
+          _ptr(partial), _ptr(grows), _ptr(inv), _ptr(dcol), _ptr(d_pos), _ptr(d_ls), _ptr(d_rot), _ptr(d_al), mode,
+          _ptr(d_sh), sh_mode, _ptr(st.prune_cost), _ptr(st.split_score), _ptr(_vis_out(st, live)))
+      _lib.check(lib.gsr_frame_backward(C.byref(args), ev[0], ev[1], _stream()), "gsr_frame_backward")
+    else:
+      dcol = torch.zeros(0, 3, dtype=torch.float32, device=dev) if want_sh else None
+    if collector is not None:              # data-parallel factor exchange: keep only the colour gradient
+      collector.items.append((indexes, dcol, cam))
+    if owner is not None:
+      owner.feature_uninitialized = False
     if go is not None:
       return (None, None, None, None, d_sh.to(ctx.in_dtypes[4]) if (d_sh is not None and sh_out is None) else None) + \
           nothing[5:]

@@ -15,7 +15,7 @@ from . import _lib
 def _ptr(t):
   if t is None or t.numel() == 0:
     return None
-  return C.c_void_p(t.data_ptr())
+  return t.data_ptr()          # plain int: the prototypes declare c_void_p
 
 
 _stream = _lib.current_stream_ptr

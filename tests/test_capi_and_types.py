@@ -40,6 +40,11 @@ def test_host_only_entry_points(built_libs):
   p = _lib.raster_params(sta.RasterConfig(antialias=True, blur_cov=0.0))
   assert abs(p.blur - 0.3) < 1e-7 and p.antialias == 1 and p.tile_size == 16 and abs(p.q_max - 9.0) < 1e-6
   assert C.sizeof(_lib.GsrRasterParamsC) == 32
+  # the ctypes mirrors of the ABI's structs have the layout the library was compiled with
+  for which, mirror in enumerate((_lib.GsrRasterParamsC, _lib.GsrSegmentsC, _lib.GsrFrameC, _lib.GsrFramePlanC,
+                                  _lib.GsrFrameResultC, _lib.GsrFrameBackwardC)):
+    assert lib.gsr_struct_bytes(which) == C.sizeof(mirror), mirror.__name__
+  assert lib.gsr_struct_bytes(6) == -1
 
 
 def test_frame_plan_lays_out_disjoint_aligned_buffers(built_libs):

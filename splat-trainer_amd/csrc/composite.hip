@@ -270,9 +270,14 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
     for (int m = 0; m < 4; ++m) {
       if (i + m < end) {                                               // wave-uniform
         const Splat s = nxt;
-        if (i + m + 1 < end) {                                         // prefetch of the next pair's row (scalar loads)
-          if constexpr (PF) nxt = load_splat_packed<C, MEDIAN>(rec, m < 3 ? rk[m + 1] : rk_next[0]);
-          else nxt = load_splat<C, MEDIAN>(rec, sorted_rank, i + m + 1);
+        if constexpr (PF) {
+          if (i + m + 1 < end) nxt = load_splat_packed<C, MEDIAN>(rec, m < 3 ? rk[m + 1] : rk_next[0]);
+        } else {
+          // prefetch of the next pair's row (scalar loads), UNCONDITIONAL -- the last pair of the list re-reads its own
+          // row -- so that `nxt` is always a fresh value and the compiler alternates register sets instead of copying
+          // the row from "next" to "current" once per pair (-16 scalar instructions per pair; K6 -2 % at 500k splats;
+          // at 3M the re-reads cost more than the copies: +2 %, so the large-frame instantiation keeps the condition)
+          nxt = load_splat<C, MEDIAN>(rec, sorted_rank, min(i + m + 1, end - 1u));
         }
         const float dxa = fx0 - s.u, dya = fy0 - s.v;
         const v2f dx2 = {dxa, dxa + 8.f};
@@ -565,6 +570,9 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
 #ifndef GSR_K7_SEG_GROUP_LOG2
 #define GSR_K7_SEG_GROUP_LOG2 5
 #endif
+#ifndef GSR_K7_UNCOND_PREFETCH   // measured: K7 -1.5 % at 500k splats, +2.5 % at 3M (the chunk ends' re-reads): off
+#define GSR_K7_UNCOND_PREFETCH 0
+#endif
 #ifndef GSR_K7_SEG_FIRST
 #define GSR_K7_SEG_FIRST 1
 #endif
@@ -699,11 +707,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
       const int pos = cbase + j;
       flags &= ~(1ull << j);
       const bool more = flags != 0ull;
+#if GSR_K7_UNCOND_PREFETCH
+      // prefetch the next contributing pair -- unconditionally (the chunk's last pair re-reads its own row), so that
+      // `nxt` is always a fresh value: no copy of the row from "next" to "current" registers per pair
+      j = more ? 63 - __builtin_clzll(flags) : j;
+      nxt = load_splat_packed<C, true>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+      inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
+#else
       if (more) {                                             // prefetch the next contributing pair
         j = 63 - __builtin_clzll(flags);
         nxt = load_splat_packed<C, true>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
         inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
       }
+#endif
       const float dxa = fx0 - s.u, dya = fy0 - s.v;
       const v2f dx2 = {dxa, dxa + 8.f};
       // Per pair and pixel the geometry gradient enters through ONE scalar, GdG = G dL/dG; what is accumulated are its

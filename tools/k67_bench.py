@@ -23,6 +23,21 @@ if which == "c2":
 else:
   g, cams = synthetic.scene_b(3_000_000, 1920, 1080, sh_degree=3, seed=1, num_cameras=8)
   cam = cams[0]
+if os.environ.get("MORTON") == "1":            # experiment: scene rows in Morton order of their positions (30-bit codes)
+  def spread(v):
+    v = v & 0x3FF
+    v = (v | (v << 16)) & 0x030000FF
+    v = (v | (v << 8)) & 0x0300F00F
+    v = (v | (v << 4)) & 0x030C30C3
+    v = (v | (v << 2)) & 0x09249249
+    return v
+  p = g.position
+  q = ((p - p.min(0).values) / (p.max(0).values - p.min(0).values).clamp_min(1e-9) * 1023.0).long()
+  code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+  perm = torch.argsort(code)
+  g = sta.Gaussians3D(position=g.position[perm].contiguous(), log_scaling=g.log_scaling[perm].contiguous(),
+                      rotation=g.rotation[perm].contiguous(), alpha_logit=g.alpha_logit[perm].contiguous(),
+                      feature=g.feature[perm].contiguous())
 g, cam = g.to("cuda"), cam.to("cuda")
 cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True,
                        segment_pairs=int(os.environ.get("SEG_PAIRS", "-1")), segment_min_pairs=int(os.environ.get("SEG_MIN", "0")))

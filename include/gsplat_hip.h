@@ -79,7 +79,7 @@ typedef struct GsrSegmentsC {
                                  length class, filled by gsr_segment_plan), or NULL: tiles in image order */
 } GsrSegmentsC;
 #define GSR_SEG_TOTAL_WORDS 272
-#define GSR_TILE_ORDER_WORDS(num_tiles) (8 * 32 * (((num_tiles) + 7) / 8))
+#define GSR_TILE_ORDER_WORDS(num_tiles) (8 * 32 * ((((num_tiles) + 127) / 128) * 16))
 
 /* sizeof of the ABI's structs as the library was compiled: 0 GsrRasterParamsC, 1 GsrSegmentsC, 2 GsrFrameC,
  * 3 GsrFramePlanC, 4 GsrFrameResultC, 5 GsrFrameBackwardC (-1 otherwise) -- for a binding to check its own layout. */

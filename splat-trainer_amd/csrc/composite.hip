@@ -153,9 +153,8 @@ struct SegDev {
 // K6 work distribution.  With one wave per tile and every tile resident at once (1080p: 8160 tiles on 8192 wave slots)
 // a SIMD's finishing time is the sum of whichever eight lists it was dealt, and the launch lasts as long as the unluckiest
 // SIMD: measured 4.6 of 8 wave slots occupied on average, the VALUs 65 % busy -- and in image order a SIMD's eight tiles
-// are neighbours, all long or all short.  So the plan kernel files every (not heavy) tile under its XCD band (the
-// contiguous tile range gsr_xcd_remap gives that XCD: neighbouring tiles keep sharing an L2) and one of 32 length classes
-// (eighths of the mean list length), and block b of the forward launch takes the (b / 8)-th tile of band b % 8 counted
+// are neighbours, all long or all short.  So the plan kernel files every (not heavy) tile under an XCD band and one of 32
+// length classes (eighths of the mean list length), and block b of the forward launch takes the (b / 8)-th tile of band b % 8 counted
 // from the longest class down: the dispatcher deals consecutive blocks across the SIMDs, so every SIMD gets its share of
 // each class.  K6 195 -> 183 us at 500k splats, 596 -> 528 us at 3M (same box).  Which slot composites a tile changes
 // nothing the tile computes: results are bit-identical to the image-order launch.  (Measured and not kept: limiting the
@@ -163,14 +162,18 @@ struct SegDev {
 // reversing every other round of 32-1024 blocks: no change; 4-8 persistent waves per SIMD pulling tiles from per-band
 // queue heads with integer atomics, tile-only arguments re-read from the kernel-argument segment so that the walk keeps
 // its registers: 190-228 us against 185, 525-590 against 526 at 3M.)
+// Bands: runs of GSR_TILE_GROUP consecutive tiles (row-major: horizontal neighbours, which share splats and so an L2) are
+// dealt to the eight XCDs in turn, so every XCD samples the whole image.  (With one contiguous eighth of the image per
+// XCD -- the first form -- a scene that fills the middle of the frame loaded the middle XCDs with 1.5x the pairs of the
+// mean: per-wave trace at 3M splats, tools/k6_trace.py.)
 #define GSR_TILE_CLASSES 32
+#define GSR_TILE_GROUP 16
 #define GSR_SEG_CLASS_COUNT(band) (16u + GSR_TILE_CLASSES * (band))     // word of seg_total: band's first class count
-__host__ __device__ inline int gsr_tile_band(int t, int n) {            // inverse of gsr_xcd_remap: the XCD that owns tile t
-  const int q = n >> 3, r = n & 7;
-  if (t < r * (q + 1)) return t / (q + 1);
-  return q ? r + (t - r * (q + 1)) / q : 7;
+__host__ __device__ inline int gsr_tile_band(int t, int n) { (void)n; return (t / GSR_TILE_GROUP) & 7; }
+// capacity of one (band, class) list = the most tiles a band can hold
+__host__ __device__ inline int gsr_tile_band_stride(int n) {
+  return (n + 8 * GSR_TILE_GROUP - 1) / (8 * GSR_TILE_GROUP) * GSR_TILE_GROUP;
 }
-__host__ __device__ inline int gsr_tile_band_stride(int n) { return (n + 7) >> 3; }
 
 // The tile of block b in the ordered launch (see GSR_TILE_CLASSES), or -1 past the end of the band's list.
 __device__ __forceinline__ int ordered_tile(const SegDev& seg, int num_tiles, uint32_t b, int lane) {
@@ -381,6 +384,10 @@ __device__ __forceinline__ void seg_alpha_pass(uint32_t sidx, const float* __res
   out[0] = P2[0].x; out[64] = P2[0].y; out[128] = P2[1].x; out[192] = P2[1].y;
 }
 
+#ifdef GSR_K6_TRACE
+// Diagnostic build only (tools/k6_trace.py): every forward wave records when and where it ran.
+__device__ uint64_t* g_k6_trace = nullptr;      // [num_tiles, 4]: start, end (s_memrealtime), hardware ids, list length | block
+#endif
 template <int C, bool VIS, bool MEDIAN, bool PF>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restrict__ rec,
                                                            const uint32_t* __restrict__ sorted_rank,
@@ -416,6 +423,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
   const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile], end = tile_range[2 * tile + 1];
+#ifdef GSR_K6_TRACE
+  const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   FwdPix<C> px;
   fwd_init<C>(px, px0, py0, W, H);
@@ -460,6 +470,15 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(const float* __restri
       if (MEDIAN) median[pix] = (p & 1) ? px.med2[h].y : px.med2[h].x;
     }
   }
+#ifdef GSR_K6_TRACE
+  if (g_k6_trace && lane == 0) {
+    uint64_t* t = g_k6_trace + 4 * (size_t)tile;
+    t[0] = trace_t0; t[1] = __builtin_amdgcn_s_memrealtime();
+    t[2] = (uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |            // HW_REG_HW_ID
+           ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);    // HW_REG_XCC_ID
+    t[3] = (uint64_t)(end - start) | ((uint64_t)blockIdx.x << 32);
+  }
+#endif
 }
 
 // Pass C of a heavy tile: the forward walk over one segment, entered with T_in = product of the preceding segments'
@@ -949,6 +968,12 @@ inline bool seg_ok(const GsrSegmentsC* sg, bool median) {
 
 extern "C" {
 
+#ifdef GSR_K6_TRACE
+int gsr_debug_set_k6_trace(uint64_t* buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_k6_trace), &buffer, sizeof(buffer)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int gsr_segment_thresholds(int32_t seg_pairs_cfg, int32_t heavy_min_cfg, int64_t O, int32_t num_tiles, int32_t needs_grad,
                            int32_t* seg_pairs_out, int32_t* heavy_min_out) {
   if (!seg_pairs_out || !heavy_min_out || num_tiles <= 0) return GSR_ERR_INVALID_ARGUMENT;
@@ -1027,7 +1052,7 @@ int gsr_composite_forward(const float* rec, const uint32_t* sorted_rank, const u
   if (!seg_ok(segments_host, med)) return GSR_ERR_INVALID_ARGUMENT;
   const SegDev seg = to_segdev(segments_host);
   const int cap = segments_host ? (int)segments_host->heavy_capacity : 0;   // blocks of the heavy-tile passes
-  const int tb = seg.tile_order ? (nt + 7) / 8 * 8 : nt;     // tile blocks (ordered form: whole rounds over the 8 XCDs)
+  const int tb = seg.tile_order ? 8 * gsr_tile_band_stride(nt) : nt;   // tile blocks (ordered form: a band's capacity per XCD)
 #define GSR_LAUNCH_TILES(CC, VV, MM, PP)                                                                               \
   composite_fwd_kernel<CC, VV, MM, PP><<<tb + cap, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, tile_range, W, H,   \
                                                                     tx, nt, rp, image_out, final_T_out, last_out,      \
@@ -1083,7 +1108,7 @@ int gsr_composite_backward(const float* rec, const uint32_t* sorted_rank, const 
   const int seg_round = 8 << GSR_K7_SEG_GROUP_LOG2;
   const uint32_t seg_blocks = segments_host ? (uint32_t)((segments_host->capacity + seg_round - 1) / seg_round * seg_round) : 0u;
   const uint32_t seg_cap = (uint32_t)(segments_host ? segments_host->capacity : 0);
-  const int grid = (nt + 7) / 8 * 8 + (int)seg_blocks;
+  const int grid = 8 * gsr_tile_band_stride(nt) + (int)seg_blocks;
   if (C == 1) composite_bwd_kernel<1><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, seg_cap, seg_blocks);
   else if (C == 2) composite_bwd_kernel<2><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, seg_cap, seg_blocks);
   else composite_bwd_kernel<3><<<grid, 64, 0, stream>>>(rec, sorted_rank, sorted_inst, pair_vis, tile_range, W, H, tx, nt, rp, final_T, last, dL_dimage, image, partial_out, seg, seg_cap, seg_blocks);

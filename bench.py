@@ -249,7 +249,7 @@ def main():
   # camera j of the batch -> rank j mod world; gradients accumulate straight into the flat collective buffer (the
   # reference accumulates into .grad over the cameras of a batch, trainer.py:500-514); + the per-point `visible`
   # accumulator (mlp_scene.py:244); the per-camera controller statistics of ALL cameras come back in camera order
-  dp = CameraShardedStep(params, world, rank, mode=args.collective)
+  dp = CameraShardedStep(params, world, rank, mode=args.collective, position_term_local=args.form != "three_call")
   bucket = dp.bucket
   batch = [c.to(dev) for c in cams[:max(world, 1)]]                       # one camera per rank per step
   target_image = torch.full((w["h"], w["w"], 3), 0.5, device=dev)

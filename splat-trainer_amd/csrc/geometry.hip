@@ -684,6 +684,53 @@ __global__ __launch_bounds__(256) void sh_bwd_multi_kernel(const float* __restri
   }
 }
 
+// The same rebuild in its streaming form (overwrite, no position term -- every rank has added its own cameras' position
+// term before the all-reduce): a block forms 256 consecutive rows in LDS (row pitch 3K+1 words: conflict-free) and
+// streams them out with fully coalesced stores, as sh_bwd_dense_kernel does; nothing but the colour-gradient blocks and
+// the positions is read.  3 M points, 8 cameras: 902 us per-thread rows -> see DESIGN.md section 6.
+template <int K>
+__global__ __launch_bounds__(256) void sh_bwd_multi_stream_kernel(const float* __restrict__ G, int64_t g_stride,
+                                                                  const float* __restrict__ cams, int64_t cam_stride,
+                                                                  int ncam, const float* __restrict__ pos, int64_t N,
+                                                                  float* __restrict__ dsh) {
+  constexpr int ROW = 3 * K, PITCH = ROW + 1;
+  __shared__ float s_rows[256 * PITCH];
+  const int64_t row0 = (int64_t)blockIdx.x * 256;
+  const int64_t i = row0 + threadIdx.x;
+  float acc[3][K];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[ch][k] = 0.f;
+  if (i < N) {
+    const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+    for (int c = 0; c < ncam; ++c) {                               // cameras in index order: the same sums on every rank
+      const float* g = G + (int64_t)c * g_stride + i * 3;
+      const float g0 = g[0], g1 = g[1], g2 = g[2];
+      if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
+      const float* cp = cams + (int64_t)c * cam_stride;
+      const float vx = px - cp[0], vy = py - cp[1], vz = pz - cp[2];
+      const float inv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
+      float Y[K];
+      gsr_sh_basis<K>(vx * inv, vy * inv, vz * inv, Y);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        acc[0][k] += g0 * Y[k]; acc[1][k] += g1 * Y[k]; acc[2][k] += g2 * Y[k];
+      }
+    }
+  }
+  float* mine = s_rows + threadIdx.x * PITCH;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int k = 0; k < K; ++k) mine[ch * K + k] = acc[ch][k];
+  __syncthreads();
+  const int64_t rows_here = (N - row0) < 256 ? (N - row0) : 256;
+  const int total = (int)rows_here * ROW;
+  float* out = dsh + row0 * ROW;
+  for (int e = threadIdx.x; e < total; e += 256) out[e] = s_rows[(e / ROW) * PITCH + (e % ROW)];
+}
+
 inline GsrRasterParams to_params(const GsrRasterParamsC* c) {
   GsrRasterParams rp;
   __builtin_memcpy(&rp, c, sizeof(rp));
@@ -982,6 +1029,16 @@ int gsr_sh_backward_multi(const float* dL_dcolors_dense, int64_t dense_stride, c
   if (N == 0 || (num_cameras == 0 && accumulate)) return GSR_OK;
   if (!dL_dcolors_dense || !camera_positions || !sh_features || !positions || !d_sh_features) return GSR_ERR_INVALID_ARGUMENT;
   const unsigned g = grid_for(N, 256);
+  if (!accumulate && !d_positions && num_cameras > 0) {            // overwrite, no position term: the streaming form
+    switch (K) {
+      case 1: sh_bwd_multi_stream_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, positions, N, d_sh_features); break;
+      case 4: sh_bwd_multi_stream_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, positions, N, d_sh_features); break;
+      case 9: sh_bwd_multi_stream_kernel<9><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, positions, N, d_sh_features); break;
+      default: sh_bwd_multi_stream_kernel<16><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, positions, N, d_sh_features); break;
+    }
+    GSR_CHECK_LAUNCH();
+    return GSR_OK;
+  }
   switch (K) {
     case 1: sh_bwd_multi_kernel<1><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;
     case 4: sh_bwd_multi_kernel<4><<<g, 256, 0, stream>>>(dL_dcolors_dense, dense_stride, camera_positions, camera_stride, num_cameras, sh_features, positions, N, d_sh_features, d_positions, accumulate); break;

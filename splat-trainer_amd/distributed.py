@@ -376,14 +376,19 @@ class CameraShardedStep:
 
   def __init__(self, params: Sequence[torch.Tensor], world_size: int, rank: int, group=None,
                mode: str = DEFAULT_COLLECTIVE, with_stats: bool = True, packed: bool = False,
-               exchange_when_single: bool = False, fused_grad_out: bool = True):
+               exchange_when_single: bool = False, fused_grad_out: bool = True, position_term_local: bool = True):
     """``packed``: exchange rows padded to the batch's largest visible count instead of the dense per-point block
     (needs a count exchange + host sync per batch).  ``exchange_when_single``: run the exchange even with one rank
     (tests: packing, the collectives on a one-rank group, rebuild and replay on a single GPU).
     ``fused_grad_out`` (default): ``render_backward`` hands ``grad_out`` on to ``render_gaussians`` /
     ``project_to_image``, whose first backward pass of a batch initialises the gradient buffers itself (every row
     written, zeros where its camera saw nothing): no zero-fill per batch.  False: the buffers are zero-filled per batch
-    and the callback may accumulate into ``param.grad`` any way it likes."""
+    and the callback may accumulate into ``param.grad`` any way it likes.
+    ``position_term_local`` (default; factor exchange only): every rank adds the position term of its own cameras'
+    colour gradient before the all-reduce -- ``render_gaussians(use_sh=True, sh_collector=...)`` does, from the Jacobian
+    its forward pass saves -- and the multi-camera rebuild neither recomputes it for all cameras on every rank nor
+    reads the coefficient rows.  False: the rebuild adds it (needed when the callback uses the three-call form, whose
+    ``evaluate_sh_at`` hands on colour gradients only).  Must be the same on every rank."""
     self.fused = bool(fused_grad_out)
     from .renderer import GradOut
     from .sh import ShFactorCollector
@@ -400,6 +405,8 @@ class CameraShardedStep:
     self.scale_max = torch.zeros(N, dtype=torch.float32, device=self.params[0].device) if self.exchange else None
     self.feature_grad = torch.empty_like(self.params[4]) if self.factor else None
     self.collector = ShFactorCollector() if self.factor else None
+    if self.collector is not None:
+      self.collector.position_term_local = bool(position_term_local)
     v = self.bucket.views
     self.grad_out = GradOut(position=v[0], log_scaling=v[1], rotation=v[2], alpha_logit=v[3],
                             feature=None if self.factor else v[4])
@@ -472,7 +479,8 @@ class CameraShardedStep:
     if self.factor:
       pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True)
       exchange_sh_factors(self.collector, list(range(len(mine))), cpr, feature, position, self.feature_grad,
-                          self.bucket.views[0], group=self.group, accumulate=False, after=pending,
+                          None if self.collector.position_term_local else self.bucket.views[0], group=self.group,
+                          accumulate=False, after=pending,
                           visible_max=max(m for _, m in counts))
     else:
       self.bucket.all_reduce(group=self.group, mode=self.mode)
@@ -548,9 +556,12 @@ class CameraShardedStep:
     width = blocks.shape[1]
     base = blocks.data_ptr()
     ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    # (every rank runs the same render path: the flag is the same everywhere; K = 1 has no position term at all)
+    position_done = self.collector.position_term_local or K == 1
     _lib.check(_lib.load().gsr_sh_backward_multi(C.c_void_p(base), width, C.c_void_p(base + 4 * 3 * N), width,
                                                  blocks.shape[0], ptr(feature.detach()), ptr(position.detach()), N, K,
-                                                 ptr(self.feature_grad), ptr(self.bucket.views[0]), 0,
+                                                 ptr(self.feature_grad),
+                                                 None if position_done else ptr(self.bucket.views[0]), 0,
                                                  _lib.current_stream_ptr()), "gsr_sh_backward_multi")
     self.collector.clear()
     dp_replay(point_state, blocks, self.camera_slots(num_cameras, position.device), N, sums=self.bucket.extra)

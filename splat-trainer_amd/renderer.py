@@ -228,6 +228,16 @@ class GradOut:
     flag, self.geometry_uninitialized = self.geometry_uninitialized, False
     return flag
 
+  def ensure_geometry_initialized(self):
+    """For a backward pass that only ADDS to a geometry buffer (the SH backward of the three-call form adds the colour
+    gradient's position term, and autograd runs it BEFORE the projection's backward): if the buffers are still declared
+    uninitialised, zero-fill them and clear the flag, so that nothing is added to garbage and the projection's backward
+    pass -- which would otherwise overwrite every row, the added term included -- accumulates instead."""
+    if self.take_geometry_uninitialized():
+      for t in (self.position, self.log_scaling, self.rotation, self.alpha_logit):
+        if t is not None:
+          t.zero_()
+
   def _check(self, name, like):
     t = getattr(self, name)
     if t is None or t.shape != like.shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != like.device:
@@ -693,7 +703,7 @@ class _FrameFn(torch.autograd.Function):
     else:
       dcol = torch.zeros(0, 3, dtype=torch.float32, device=dev) if want_sh else None
     if collector is not None:              # data-parallel factor exchange: keep only the colour gradient
-      collector.items.append((indexes, dcol, cam))
+      collector.items.append((indexes, dcol, cam))      # (position_term_local: the sweep above added the position term)
     if owner is not None:
       owner.feature_uninitialized = False
     if go is not None:
@@ -798,8 +808,14 @@ def _render_frame(gaussians: Gaussians3D, camera_params: CameraParams, config: R
       t.requires_grad for t in (position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit, feature)))
   cull_args = (int(W), int(H), float(camera_params.near_plane), float(camera_params.far_plane),
                float(config.margin_tiles * config.tile_size))
+  # the colour gradient's position term: from the Jacobian the forward pass saves.  Also in data-parallel mode (factor
+  # collector): every rank adds the term of its own cameras before the all-reduce, so the multi-camera rebuild does not
+  # have to recompute it for all cameras on every rank (it would re-read every coefficient row for that)
+  want_pos_grad = _sh.wants_position_grad(position, sh_out) or (
+      sh_collector is not None and sh_collector.position_term_local and torch.is_grad_enabled() and
+      (position.requires_grad or grad_out is not None))
   image, g2d, depth, indexes = _FrameFn.apply(position, gaussians.log_scaling, gaussians.rotation, gaussians.alpha_logit,
                                               feature, _f32c(camera_params.T_camera_world),
                                               _f32c(camera_params.projection), camera_params.camera_position, cull_args,
-                                              st, grad_out, sh_out, _sh.wants_position_grad(position, sh_out))
+                                              st, grad_out, sh_out, want_pos_grad)
   return _rendering_of(st, image, indexes, g2d, depth, camera_params)

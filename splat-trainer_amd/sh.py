@@ -29,6 +29,12 @@ class ShFactorCollector:
 
   def __init__(self):
     self.items = []            # (indexes (M,), d_colour (M,3), camera_pos (3,)) in the order backward ran
+    # Configuration, the same on every rank (distributed.CameraShardedStep sets it): True = every rank adds the position
+    # term of its OWN cameras' colour gradient to the position gradient before the all-reduce (render_gaussians' fused
+    # node does, from the Jacobian its forward pass saves), so the multi-camera rebuild leaves the position gradient
+    # alone and never reads the coefficient rows; False = the rebuild recomputes the term for all cameras on every rank
+    # (what the three-call form needs: evaluate_sh_at hands on colour gradients only).
+    self.position_term_local = False
 
   def clear(self):
     self.items.clear()
@@ -89,6 +95,9 @@ class _SHFn(torch.autograd.Function):
     M = idx.shape[0]
     go = ctx.grad_out
     if isinstance(go, ShFactorCollector):    # data-parallel factor exchange: keep only the colour gradient
+      if go.position_term_local and K > 1:
+        raise _lib.GsplatHipError("evaluate_sh_at cannot add the colour gradient's position term locally: use "
+                                  "render_gaussians(use_sh=True, sh_collector=...) or CameraShardedStep(position_term_local=False)")
       go.items.append((idx, d_out.detach().to(torch.float32).contiguous(), cam))
       return None, None, None, None, None, None, None
     g = d_out.detach().to(torch.float32).contiguous() if M > 0 else None
@@ -96,6 +105,8 @@ class _SHFn(torch.autograd.Function):
     overwrite = go is None or (owner is not None and owner.feature_uninitialized)
     if go is not None:                       # fused "+=" into caller-owned buffers (see renderer.GradOut)
       d_sh, d_pos = go[0], go[1]
+      if owner is not None and d_pos is not None and K > 1:
+        owner.ensure_geometry_initialized()  # this pass adds to d_pos and runs before the projection's backward pass
     else:
       d_sh = torch.empty(N, 3, K, dtype=torch.float32, device=pos.device)
       d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[1] else None

@@ -220,3 +220,39 @@ def test_transfer_sh_flow():
       opt.step()
       losses.append(float(loss.detach()))
   assert losses[-1] < 0.1 * losses[0] and all(torch.isfinite(p).all() for p in (base_sh, higher_sh))
+
+
+@pytest.mark.parametrize("form", ["three_call", "one_call"])
+def test_fused_gradient_buffers_declared_uninitialised_get_every_term(form):
+  """GradOut(geometry_uninitialized=True, feature_uninitialized=True): buffers full of garbage, no zero-fill by the
+  caller.  In the three-call form autograd runs the SH backward (which ADDS the colour gradient's position term) before
+  the projection's backward (which would overwrite every row): every term must still arrive, as with plain autograd."""
+  g, cam = small_scene(3000, 160, 120, sh_degree=2, seed=21, sigma_px=3.0)
+  cam = cam.to("cuda")
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  target = torch.full((120, 160, 3), 0.4, device="cuda")
+
+  def run(grad_out):
+    params = [t.clone().cuda().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+    scene = sta.Gaussians3D(position=params[0], log_scaling=params[1], rotation=params[2], alpha_logit=params[3],
+                            feature=params[4])
+    go = None
+    if grad_out:
+      bufs = [torch.full_like(p, 123.0) for p in params]               # garbage the backward pass must not keep
+      go = sta.GradOut(position=bufs[0], log_scaling=bufs[1], rotation=bufs[2], alpha_logit=bufs[3], feature=bufs[4],
+                       feature_uninitialized=True, geometry_uninitialized=True)
+    with torch.enable_grad():
+      if form == "one_call":
+        r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=go)
+      else:
+        g2d, depth, idx = sta.project_to_image(scene, cam, cfg, grad_out=go)
+        sh_out = (go.feature, go.position, go) if go is not None else None
+        feats = sta.evaluate_sh_at(params[4], params[0], idx, cam.camera_position, grad_out=sh_out)
+        r = sta.render_projected(idx, g2d, feats, depth, cam, cfg)
+      sta.clamped_mse_loss(r.image, target).backward()
+    return bufs if grad_out else [p.grad for p in params]
+
+  want, got = run(False), run(True)
+  for name, a, b in zip(("position", "log_scaling", "rotation", "alpha_logit", "feature"), got, want):
+    assert rel_err(a, b) < 1e-6, name
+  assert want[0].abs().max() > 0

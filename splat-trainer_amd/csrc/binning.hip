@@ -37,58 +37,107 @@ struct TileHits {            // 16 bytes per depth rank
   uint32_t lo, hi;           // the map
 };
 
-__device__ __forceinline__ uint32_t hits_of_large_extent(float u, float v, float A, float B, float C, const GsrExtent& e,
-                                                         uint32_t* keys, uint32_t* ranks, uint32_t o, uint32_t capacity,
-                                                         uint32_t k, int tiles_x) {
+// A large extent (more than 32 tiles: splats tens to hundreds of pixels wide, which a training run grows sooner or later)
+// is tested by the WHOLE WAVE, 64 tiles of the extent at a time in row-major order -- one thread walking the extent of a
+// screen-filling splat (8160 tiles at 1080p) would hold its wave, and with it the launch, for a millisecond: measured on
+// the c4 loop, tile_count 73 -> 1245 us and tile_emit 32 -> 1550 us per frame once a few splats had grown that large.
+// All arguments are wave-uniform.  Returns the number of tiles hit (to every lane); with `keys` the hits are also written
+// to the slots [o, o + n) in row-major order (ballot-ranked: exactly the order a sequential walk gives).
+__device__ __forceinline__ uint32_t hits_of_large_extent(float u, float v, float A, float B, float C, float qmax, int x0,
+                                                         int x1, int y0, int y1, uint32_t* keys, uint32_t* ranks,
+                                                         uint32_t o, uint32_t capacity, uint32_t k, int tiles_x,
+                                                         int lane) {
+  const int nx = x1 - x0, total = nx * (y1 - y0);
   uint32_t n = 0;
-  for (int ty = e.y0; ty < e.y1; ++ty)
-    for (int tx = e.x0; tx < e.x1; ++tx) {
-      if (!gsr_tile_hit(u, v, A, B, C, e.qmax, tx, ty)) continue;       // cheap rejection first: these extents are big
-      const uint32_t hm = gsr_tile_half_mask(u, v, A, B, C, e.qmax, tx, ty);
-      if (!hm) continue;
-      if (keys) {
-        if (o + n >= capacity) return n;      // speculative launch into buffers sized from a guess: the caller re-emits
-        keys[o + n] = (uint32_t)(ty * tiles_x + tx);
-        ranks[o + n] = k | (hm << 30);        // splat id in the low 30 bits, the tile halves reached in the top 2
-      }
-      ++n;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int t = t0 + lane;
+    uint32_t hm = 0u;
+    int tx = 0, ty = 0;
+    if (t < total) {
+      ty = y0 + t / nx;
+      tx = x0 + t % nx;
+      if (gsr_tile_hit(u, v, A, B, C, qmax, tx, ty)) hm = gsr_tile_half_mask(u, v, A, B, C, qmax, tx, ty);
     }
+    const uint64_t hit = __ballot(hm != 0u);
+    if (keys && hm) {
+      const uint32_t at = o + n + (uint32_t)gsr_mbcnt(hit);
+      if (at < capacity) {                    // speculative launch into buffers sized from a guess: the caller re-emits
+        keys[at] = (uint32_t)(ty * tiles_x + tx);
+        ranks[at] = k | (hm << 30);           // splat id in the low 30 bits, the tile halves reached in the top 2
+      }
+    }
+    n += (uint32_t)__builtin_popcountll(hit);
+  }
   return n;
 }
 
-// One depth rank's tile count and hit record (see TileHits).
+__device__ __forceinline__ float gsr_bcast(float x, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
+// The wave's large extents, one after the other: every lane that flagged one (`large`) has its splat's geometry
+// broadcast and its tiles counted / emitted by all 64 lanes.  Must be reached by every lane of the wave.
+__device__ __forceinline__ uint32_t wave_large_extents(bool large, float u, float v, float A, float B, float C,
+                                                       const GsrExtent& e, uint32_t* keys, uint32_t* ranks, uint32_t o,
+                                                       uint32_t capacity, uint32_t sid, int tiles_x, int lane) {
+  uint32_t mine = 0u;
+  uint64_t todo = __ballot(large);
+  while (todo) {
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const uint32_t n = hits_of_large_extent(
+        gsr_bcast(u, l), gsr_bcast(v, l), gsr_bcast(A, l), gsr_bcast(B, l), gsr_bcast(C, l), gsr_bcast(e.qmax, l),
+        __builtin_amdgcn_readlane(e.x0, l), __builtin_amdgcn_readlane(e.x1, l), __builtin_amdgcn_readlane(e.y0, l),
+        __builtin_amdgcn_readlane(e.y1, l), keys, ranks, (uint32_t)__builtin_amdgcn_readlane((int)o, l), capacity,
+        (uint32_t)__builtin_amdgcn_readlane((int)sid, l), tiles_x, lane);
+    if (lane == l) mine = n;
+  }
+  return mine;
+}
+
+// One depth rank's tile count and hit record (see TileHits).  `live` false: a lane without a rank (it only takes part
+// in the wave's cooperative passes).
 __device__ __forceinline__ uint32_t tile_count_one(const float* __restrict__ rows, const uint32_t* __restrict__ order,
-                                                   int64_t k, int tiles_x, int tiles_y, const GsrRasterParams& rp,
-                                                   TileHits* __restrict__ hits) {
-  const int64_t s = order[k];
-  const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * s);
-  const float4 r0 = r[0];
-  const float4 r1 = r[1];
-  const float2 uv = make_float2(r0.x, r0.y), ab = make_float2(r0.z, r0.w), co = make_float2(r1.x, r1.y);
-  const GsrExtent e = gsr_splat_extent(uv.x, uv.y, ab.x, ab.y, co.x, co.y, rp, tiles_x, tiles_y);
-  const int nx = e.x1 - e.x0, ny = e.y1 - e.y0;
+                                                   int64_t k, bool live, int tiles_x, int tiles_y,
+                                                   const GsrRasterParams& rp, TileHits* __restrict__ hits) {
+  float2 uv = make_float2(0.f, 0.f), ab = uv, co = uv;
+  GsrExtent e;
+  e.x0 = e.x1 = e.y0 = e.y1 = 0; e.qmax = 0.f;
   TileHits h;
-  h.origin = (uint32_t)e.x0 | ((uint32_t)e.y0 << 16);
-  h.shape = 0u; h.lo = 0u; h.hi = 0u;
+  h.origin = 0u; h.shape = 0u; h.lo = 0u; h.hi = 0u;
   uint32_t n = 0;
-  if (nx > 0 && ny > 0) {
-    if (nx * ny <= 32) {
-      h.shape = (uint32_t)nx | ((uint32_t)ny << 8);
-      uint64_t map = 0ull;
-      int t = 0;
-      for (int ty = e.y0; ty < e.y1; ++ty)
-        for (int tx = e.x0; tx < e.x1; ++tx, ++t) {
-          const uint64_t hm = gsr_tile_half_mask(uv.x, uv.y, ab.x, ab.y, co.x, e.qmax, tx, ty);
-          map |= hm << (2 * t);
-          n += hm ? 1u : 0u;
-        }
-      h.lo = (uint32_t)map; h.hi = (uint32_t)(map >> 32);
-    } else {
-      h.shape = 1u << 16;
-      n = hits_of_large_extent(uv.x, uv.y, ab.x, ab.y, co.x, e, nullptr, nullptr, 0u, 0u, 0u, tiles_x);
+  bool large = false;
+  if (live) {
+    const int64_t s = order[k];
+    const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * s);
+    const float4 r0 = r[0];
+    const float4 r1 = r[1];
+    uv = make_float2(r0.x, r0.y); ab = make_float2(r0.z, r0.w); co = make_float2(r1.x, r1.y);
+    e = gsr_splat_extent(uv.x, uv.y, ab.x, ab.y, co.x, co.y, rp, tiles_x, tiles_y);
+    const int nx = e.x1 - e.x0, ny = e.y1 - e.y0;
+    h.origin = (uint32_t)e.x0 | ((uint32_t)e.y0 << 16);
+    if (nx > 0 && ny > 0) {
+      if (nx * ny <= 32) {
+        h.shape = (uint32_t)nx | ((uint32_t)ny << 8);
+        uint64_t map = 0ull;
+        int t = 0;
+        for (int ty = e.y0; ty < e.y1; ++ty)
+          for (int tx = e.x0; tx < e.x1; ++tx, ++t) {
+            const uint64_t hm = gsr_tile_half_mask(uv.x, uv.y, ab.x, ab.y, co.x, e.qmax, tx, ty);
+            map |= hm << (2 * t);
+            n += hm ? 1u : 0u;
+          }
+        h.lo = (uint32_t)map; h.hi = (uint32_t)(map >> 32);
+      } else {
+        h.shape = 1u << 16;
+        large = true;
+      }
     }
   }
-  *reinterpret_cast<uint4*>(hits + k) = make_uint4(h.origin, h.shape, h.lo, h.hi);
+  const uint32_t nl = wave_large_extents(large, uv.x, uv.y, ab.x, ab.y, co.x, e, nullptr, nullptr, 0u, 0u, 0u, tiles_x,
+                                         gsr_lane());
+  if (large) n = nl;
+  if (live) *reinterpret_cast<uint4*>(hits + k) = make_uint4(h.origin, h.shape, h.lo, h.hi);
   return n;
 }
 
@@ -102,26 +151,19 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ M_dev,
                                                          uint32_t* __restrict__ block_sums) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // (M may be a capacity with the visible count still on the device: ranks behind it count zero tiles, so the scan over
+  // the capacity needs no count of its own; every lane stays for the wave's cooperative pass over large extents)
+  const bool live = k < M && !(M_dev && k >= (int64_t)*M_dev);
+  uint32_t n = tile_count_one(rows, order, k, live, tiles_x, tiles_y, rp, hits);
+  if (k < M) count[k] = n;
   if (block_sums) {
     // also leaves the block's total for offsets_from_sums_kernel (the scan's reduce pass, folded in here)
     __shared__ uint32_t s_wave[4];
-    uint32_t n = 0u;
-    if (k < M) {
-      if (!(M_dev && k >= (int64_t)*M_dev)) n = tile_count_one(rows, order, k, tiles_x, tiles_y, rp, hits);
-      count[k] = n;
-    }
     n = gsr_wave_sum_u32(n);
     if (gsr_lane() == 0) s_wave[threadIdx.x >> 6] = n;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
-    return;
   }
-  if (k >= M) return;
-  if (M_dev && k >= (int64_t)*M_dev) {        // M is a capacity: the visible count is still on the device
-    count[k] = 0u;                            // the scan over the capacity then needs no count of its own
-    return;
-  }
-  count[k] = tile_count_one(rows, order, k, tiles_x, tiles_y, rp, hits);
 }
 
 // offsets = exclusive scan of count, from the per-256 totals tile_count_kernel left: a block scans 4096 counts and adds
@@ -184,18 +226,27 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(const float* __restrict_
                                                         uint32_t* __restrict__ inst2splat, uint32_t capacity,
                                                         const uint32_t* __restrict__ M_dev) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= M || (M_dev && k >= (int64_t)*M_dev)) return;
-  const uint4 hw = *reinterpret_cast<const uint4*>(hits + k);
-  uint32_t o = offsets[k];
-  const uint32_t sid = order[k];
-  if (hw.y >> 16) {                           // extent too large for the map: test again, exactly as the count pass did
-    const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * (int64_t)sid);
-    const float4 r0 = r[0];
-    const float4 r1 = r[1];
-    const GsrExtent e = gsr_splat_extent(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rp, tiles_x, tiles_y);
-    hits_of_large_extent(r0.x, r0.y, r0.z, r0.w, r1.x, e, keys, inst2splat, o, capacity, sid, tiles_x);
-    return;
+  const bool live = k < M && !(M_dev && k >= (int64_t)*M_dev);
+  uint4 hw = make_uint4(0u, 0u, 0u, 0u);
+  uint32_t o = 0u, sid = 0u;
+  if (live) {
+    hw = *reinterpret_cast<const uint4*>(hits + k);
+    o = offsets[k];
+    sid = order[k];
   }
+  // extents too large for the map: tested again, exactly as the count pass did, by the whole wave
+  const bool large = (hw.y >> 16) != 0u;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  GsrExtent e;
+  e.x0 = e.x1 = e.y0 = e.y1 = 0; e.qmax = 0.f;
+  if (large) {
+    const float4* r = reinterpret_cast<const float4*>(rows + GSR_ROW_FLOATS * (int64_t)sid);
+    r0 = r[0];
+    r1 = r[1];
+    e = gsr_splat_extent(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rp, tiles_x, tiles_y);
+  }
+  wave_large_extents(large, r0.x, r0.y, r0.z, r0.w, r1.x, e, keys, inst2splat, o, capacity, sid, tiles_x, gsr_lane());
+  if (!live || large) return;
   const int nx = (int)(hw.y & 0xFFu), ny = (int)((hw.y >> 8) & 0xFFu);
   const int x0 = (int)(hw.x & 0xFFFFu), y0 = (int)(hw.x >> 16);
   uint64_t map = (uint64_t)hw.z | ((uint64_t)hw.w << 32);
@@ -221,8 +272,16 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
   if (i == O - 1 || keys[i + 1] != t) range[2 * t + 1] = (uint32_t)(i + 1);
 }
 
-// Instances of rank k occupy the contiguous pre-sort ids [offsets[k], offsets[k] + count[k]); summing them in id
-// order gives a fixed association order -> bit-reproducible results (no float atomics anywhere on this path).
+// Instances of rank k occupy the contiguous pre-sort ids [offsets[k], offsets[k] + count[k]).  Their sum has ONE
+// association order, whoever forms it (reduce_vis_kernel, reduce_grad_kernel: same bits; no float atomics anywhere on
+// this path -> bit-reproducible results):
+//   * up to GSR_REDUCE_SERIAL slots: added one after the other in id order;
+//   * more (a splat that reaches more than 64 tiles): the slots are taken in groups of 64 counted from the rank's FIRST
+//     slot, a group is summed over the wave by the fixed tree of gsr_wave_sum_to_lane63 (missing slots count 0), and the
+//     group sums are added one after the other in group order.  One thread adding the 8160 slots of a screen-filling
+//     splat held its block for 100+ us (c4 loop: reduce_grad 113 -> 670 us per frame once splats had grown).
+#define GSR_REDUCE_SERIAL 64u
+
 __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict__ vis_partial,
                                                          const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ count,
@@ -230,23 +289,39 @@ __global__ __launch_bounds__(256) void reduce_vis_kernel(const float* __restrict
                                                          float* __restrict__ vis, uint32_t limit,
                                                          const uint32_t* __restrict__ M_dev) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= M || (M_dev && k >= (int64_t)*M_dev)) return;
-  const uint32_t b = offsets[k], n = count[k];
+  const bool live = k < M && !(M_dev && k >= (int64_t)*M_dev);
+  const uint32_t b = live ? offsets[k] : 0u, n = live ? count[k] : 0u;
+  const int lane = gsr_lane();
   float acc = 0.f;
   // limit = slots vis_partial holds: a speculative launch (buffers sized from a guess that turned out too small) must
   // not read past them; its output is discarded by the caller
-  for (uint32_t j = 0; j < n && b + j < limit; ++j) acc += vis_partial[b + j];
-  vis[order ? order[k] : (uint32_t)k] = acc;
+  if (n <= GSR_REDUCE_SERIAL)
+    for (uint32_t j = 0; j < n && b + j < limit; ++j) acc += vis_partial[b + j];
+  uint64_t todo = __ballot(n > GSR_REDUCE_SERIAL);
+  while (todo) {                                               // the wave's large ranks, one after the other
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)b, l), nl = (uint32_t)__builtin_amdgcn_readlane((int)n, l);
+    float total = 0.f;                                         // (only lane 63's copy is meaningful)
+    for (uint32_t g = 0; g < nl; g += 64u) {
+      const uint32_t j = g + (uint32_t)lane;
+      const float v = (j < nl && bl + j < limit) ? vis_partial[bl + j] : 0.f;
+      total += gsr_wave_sum_to_lane63(v);
+    }
+    const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(total), 63));
+    if (lane == l) acc = t;
+  }
+  if (live) vis[order ? order[k] : (uint32_t)k] = acc;
 }
 
 // One block = 256 consecutive depth ranks = one CONTIGUOUS range of instance slots.  The range is streamed through
 // LDS in 256-slot chunks with fully coalesced 16-byte loads; each thread then adds the slots of its own rank from
-// LDS in ascending id order (fixed association order -> bit-reproducible).
+// LDS in ascending id order (large ranks: by the whole wave afterwards, see above).
 // The per-splat sums leave as ONE packed 64-byte row per splat, written whole by its thread (a full line: no partial
 // write, no read-modify-write) at the splat's id -- the only crossing of the depth-order permutation on the backward
 // side:   mx my mxx mxy | myy dop prune split | df0 df1 df2 visibility | 0 0 0 0   (m*: moments of G dL/dG about the
 // mean, composite.hip K7; the sweep in splat order that reads the rows turns them into d(u, v, A, B, C)).
-// The visibility column is the sum of the forward pass's per-pair partials in the same id order reduce_vis_kernel uses
+// The visibility column is the sum of the forward pass's per-pair partials in the same order reduce_vis_kernel uses
 // (same bits), so a frame that is back-propagated needs no separate visibility reduction.
 __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restrict__ partial,
                                                           const float* __restrict__ vis_partial,
@@ -262,6 +337,7 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
   const int64_t k = k0 + threadIdx.x;
   const bool have = k < M;
   const uint32_t b = have ? offsets[k] : 0u, n = have ? count[k] : 0u;
+  const bool serial = n <= GSR_REDUCE_SERIAL;
   if (threadIdx.x == 0) s_lo = b;
   const int64_t klast = (k0 + 255 < M ? k0 + 255 : M - 1);
   if (k == klast) s_hi = b + n;
@@ -283,7 +359,7 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
       if (f < 3 * m && s_vis[f / 3] > 0.f) s_part[f] = src[(size_t)3 * c + f];
     }
     __syncthreads();
-    const uint32_t j0 = max(b, c), j1 = min(b + n, c + m);
+    const uint32_t j0 = max(b, c), j1 = serial ? min(b + n, c + m) : 0u;
     for (uint32_t j = j0; j < j1; ++j) {
       const uint32_t l = j - c;
       const float pv = s_vis[l];
@@ -296,6 +372,40 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* __restric
       }
     }
     __syncthreads();
+  }
+  // the wave's large ranks, one after the other, straight from global memory: lane i takes slot g + i of each group
+  const int lane = gsr_lane();
+  uint64_t todo = __ballot(!serial);
+  while (todo) {
+    const int l = __builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)b, l), nl = (uint32_t)__builtin_amdgcn_readlane((int)n, l);
+    float t[12];                                               // (only lane 63's copies are meaningful)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) t[i] = 0.f;
+    for (uint32_t g = 0; g < nl; g += 64u) {
+      const uint32_t j = g + (uint32_t)lane;
+      const float pv = j < nl ? vis_partial[bl + j] : 0.f;
+      float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+      if (pv > 0.f) {
+        const float4* q = src + (size_t)3 * (bl + j);
+        p0 = q[0]; p1 = q[1]; p2 = q[2];
+      }
+      t[0] += gsr_wave_sum_to_lane63(p0.x); t[1] += gsr_wave_sum_to_lane63(p0.y);
+      t[2] += gsr_wave_sum_to_lane63(p0.z); t[3] += gsr_wave_sum_to_lane63(p0.w);
+      t[4] += gsr_wave_sum_to_lane63(p1.x); t[5] += gsr_wave_sum_to_lane63(p1.y);
+      t[6] += gsr_wave_sum_to_lane63(p1.z); t[7] += gsr_wave_sum_to_lane63(p1.w);
+      t[8] += gsr_wave_sum_to_lane63(p2.x); t[9] += gsr_wave_sum_to_lane63(p2.y);
+      t[10] += gsr_wave_sum_to_lane63(p2.z); t[11] += gsr_wave_sum_to_lane63(pv);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) t[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t[i]), 63));
+    if (lane == l) {
+      a0 = make_float4(t[0], t[1], t[2], t[3]);
+      a1 = make_float4(t[4], t[5], t[6], t[7]);
+      a2 = make_float4(t[8], t[9], t[10], 0.f);
+      vsum = t[11];
+    }
   }
   if (!have) return;
   const int64_t s = order ? (int64_t)order[k] : k;           // order == NULL: ranks are splat ids already

@@ -463,10 +463,16 @@ class CameraShardedStep:
       self.bucket.extra[:N].index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
       if self.with_stats:
         local.append(point_stats_of(j, r.points))
-    if self.grad_out.geometry_uninitialized:   # this rank had no camera in the batch: its share of the sum is zero
+    # A slot whose flag is still set was never written (this rank had no camera in the batch, or none of its cameras
+    # reached that buffer): its share of the sum is zero -- and it must BE zero before a collective adds it to the others
+    if self.grad_out.geometry_uninitialized:
       self.grad_out.geometry_uninitialized = False
       for v in self.bucket.views[:4]:
         v.zero_()
+    if self.grad_out.feature_uninitialized:
+      self.grad_out.feature_uninitialized = False
+      if self.grad_out.feature is not None:
+        self.grad_out.feature.zero_()
     if not self.exchange:
       return [] if light else local
     if dense:

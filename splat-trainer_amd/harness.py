@@ -122,7 +122,9 @@ class MiniTrainer:
   def optimizer_step(self):
     """mlp_scene.py:214-239."""
     pts = self.points
-    vis_idx = pts.visible.nonzero().squeeze(1)
+    vis_idx = pts.visible.nonzero().squeeze(1)          # (the iteration's one host wait: the row count sizes the step)
+    if vis_idx.shape[0] == 0:
+      raise RuntimeError("No visible points")           # trainer.py:507-509, for the batch as a whole
     if pts.log_scaling.is_cuda:          # one launch instead of the expression's dozen (0.1 instead of 1 ms at 3 M rows)
       basis = point_basis_rows(pts.log_scaling, pts.rotation, vis_idx)
     else:
@@ -151,24 +153,28 @@ class MiniTrainer:
     return GradOut(feature_uninitialized=True, geometry_uninitialized=True, **grads)
 
   def training_step(self) -> float:
-    """trainer.py:531-545: evaluate_backward_with over the batch, then the optimizer step."""
-    total = 0.0
+    """trainer.py:531-545: evaluate_backward_with over the batch, then the optimizer step.  The host waits for the
+    device ONCE per iteration (the optimizer's ``visible.nonzero()``): the per-camera losses are added up on the device
+    and read afterwards, and the reference's "no visible points" guard (trainer.py:507-509, ``points.num_visible`` -- a
+    reduction and a read-back per camera, in front of the backward pass) is split into its host-known half here (no
+    point in view: M = 0) and the batch-wide half in ``optimizer_step`` (no point of the batch has visibility > 0)."""
     fused = self.device.type == "cuda"
     grad_out = self._grad_target() if fused else None
+    total = torch.zeros((), dtype=torch.float32, device=self.device)
     for cam, target in zip(self.cameras, self.targets):
       with torch.enable_grad():
         r = render_gaussians(self.scene(), cam, self.config, use_sh=True, grad_out=grad_out)
-        if r.points.num_visible == 0:
+        if r.points.idx.shape[0] == 0:
           raise RuntimeError("No visible points")                     # trainer.py:507-509
         loss = clamped_mse_loss(r.image, target) if fused else F.mse_loss(r.image.clamp(0, 1), target)
         loss.backward()
       with torch.no_grad():
         # point_state.py:34-50 (camera order) and mlp_scene.py:244 (visible[idx] += visibility) in one launch
         self.state.add_rendering(r, visible_sum=self.points.visible)
-      total += float(loss.item())
+        total += loss.detach()
     self.optimizer_step()
     self.step_idx += 1
-    self.log.losses.append(total / len(self.cameras))
+    self.log.losses.append(float(total.item()) / len(self.cameras))
     self.log.num_points.append(self.num_points)
     if self.densify_every and self.step_idx % self.densify_every == 0 and self.step_idx < self.total_steps:
       self.densify_and_prune()

@@ -268,3 +268,46 @@ def test_two_rank_point_stats_and_packed_factors(tmp_path, num_cameras):
     assert torch.equal(torch.nan_to_num(b, nan=-1.0), torch.nan_to_num(r0["blocks"], nan=-1.0))
     for f in ("prune_cost", "split_score", "max_scale_px"):
       assert torch.equal(r["replayed"][f], getattr(twice, f)), f
+
+
+def _idle_rank_worker(rank, world, port, out_path):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  import splat_trainer_amd as sta
+  from splat_trainer_amd.distributed import CameraShardedStep
+  n = 40
+  params = [torch.zeros(n, d, requires_grad=True) for d in (3, 3, 4, 1)] + [torch.zeros(n, 3, 4, requires_grad=True)]
+  dp = CameraShardedStep(params, world, rank, mode="all_reduce", with_stats=False)      # fused_grad_out: the default
+  dp.bucket.flat.fill_(float("nan"))                        # what an uninitialised buffer may hold
+
+  def fake_render(j, cam, grad_out, collector):
+    # the renderer's first backward pass of a batch: writes every row of every buffer and clears both flags
+    assert grad_out.geometry_uninitialized and grad_out.feature_uninitialized
+    for k, name in enumerate(("position", "log_scaling", "rotation", "alpha_logit", "feature")):
+      getattr(grad_out, name).fill_(float(k + 1))
+    grad_out.geometry_uninitialized = grad_out.feature_uninitialized = False
+    idx = torch.arange(n)
+    z = torch.zeros(n)
+    return sta.Rendering(image=None, camera=None, points=sta.RenderedPoints(
+        idx=idx, depths=z[:, None], opacity=z, screen_scale=torch.ones(n, 2), visibility=torch.ones(n), prune_cost=z,
+        split_score=z))
+
+  dp.run([0], fake_render)                                  # ONE camera, two ranks: rank 1 renders nothing
+  torch.save({k: v.clone() for k, v in dp.grads.items()}, f"{out_path}.{rank}")
+  assert not dp.grad_out.geometry_uninitialized and not dp.grad_out.feature_uninitialized
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rank_without_camera_contributes_zeros_to_every_gradient_slot(tmp_path):
+  """CameraShardedStep(mode="all_reduce", fused_grad_out=True) with fewer cameras than ranks: the idle rank's buffers --
+  all five slots, the feature gradient included -- were declared uninitialised and never written, so they must be
+  zero-filled before the all-reduce adds them to the other ranks' gradients."""
+  world, port = 2, 35000 + (os.getpid() % 2000)
+  out = str(tmp_path / "idle")
+  mp.spawn(_idle_rank_worker, args=(world, port, out), nprocs=world, join=True)
+  r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+  for k, name in enumerate(("position", "log_scaling", "rotation", "alpha_logit", "feature")):
+    assert torch.all(r0[name] == float(k + 1)), name
+    assert torch.equal(r0[name], r1[name]), name

@@ -669,3 +669,38 @@ def test_depth_key_range_follows_the_camera_planes(near, far):
   assert torch.equal(got["idx"], want["idx"]) and got["num_overlaps"] == want["num_overlaps"]
   for k in ("image", "visibility", "split_score", "prune_cost") + GRADS:
     assert torch.equal(got[k], want[k]), k
+
+
+def _scene_with_giants(n=3000, w=320, h=240, giants=40, seed=11):
+  g, cam = small_scene(n, w, h, sh_degree=1, seed=seed, sigma_px=2.5)
+  gen = torch.Generator().manual_seed(seed)
+  pick = torch.randperm(n, generator=gen)[:giants]
+  ls, al = g.log_scaling.clone(), g.alpha_logit.clone()
+  ls[pick] += 3.0 + torch.rand(giants, 1, generator=gen)            # x20 .. x55: supports of 40 .. 300 tiles, several
+  al[pick] = -3.0 + torch.rand(giants, 1, generator=gen)            # fill the frame; faint, so the scene behind them still counts
+  return sta.Gaussians3D(g.position, g.rotation, ls, al, g.feature), cam
+
+
+def test_large_splats_take_the_cooperative_paths_and_match_oracle():
+  """Splats that reach tens to hundreds of tiles (a training run grows them: c4) are counted / emitted by the whole wave
+  and their per-(tile, splat) partials summed group-wise (binning.hip: GSR_REDUCE_SERIAL) instead of by one thread:
+  against the oracle everywhere, run-to-run bit-identical, and the stand-alone visibility reduction gives the bits the
+  backward pass's reduction gives."""
+  g, cam = _scene_with_giants()
+  hip = hip_render_and_grads(g, cam, CFG, use_sh=True)
+  assert hip["num_overlaps"] > 40 * 100, hip["num_overlaps"]          # the giants really are there
+  orc = oracle_render_and_grads(g, cam, CFG, use_sh=True)
+  _compare(hip, orc)
+  again = hip_render_and_grads(g, cam, CFG, use_sh=True)
+  for k in ("image", "visibility", "prune_cost", "split_score") + GRADS:
+    assert torch.equal(hip[k], again[k]), k
+  # visibility read BEFORE backward (reduce_vis_kernel) == the column the backward pass's reduction delivers
+  camd = cam.to("cuda")
+  gd = sta.Gaussians3D(*(t.clone().cuda().requires_grad_(True) for t in
+                         (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
+  r = sta.render_gaussians(gd, camd, CFG, use_sh=True)
+  early = r.points.visibility.clone()
+  ((r.image.clamp(0, 1) - 0.5) ** 2).mean().backward()
+  assert torch.equal(early, hip["visibility"])
+  with torch.no_grad():
+    assert torch.equal(sta.render_gaussians(gd, camd, CFG, use_sh=True).points.visibility, hip["visibility"])

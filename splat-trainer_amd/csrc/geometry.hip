@@ -236,6 +236,28 @@ __device__ __forceinline__ float gsr_qlim(float opacity, const GsrRasterParams& 
   return fminf(rp.q_max, 2.f * logf(opacity / rp.alpha_threshold));
 }
 
+// Pixel bounding box of a splat's support, for the rows' words 12 / 13 (x0 | x1 << 16, y0 | y1 << 16; signed 16-bit pixel
+// coordinates, inclusive; x0 > x1: empty): every pixel whose centre passes the composite kernels' test q <= qlim lies
+// inside -- the half-widths are gsr_splat_extent's (the same inflated support K4 bins with).  Read by the windowed
+// backward walk (composite.hip: composite_bwd_win_kernel), which evaluates 64-pixel windows laid over box-and-tile.
+__device__ __forceinline__ float2 gsr_pixel_bbox(float u, float v, float A, float B, float C, float opacity,
+                                                 const GsrRasterParams& rp) {
+  int x0 = 1, x1 = 0, y0 = 1, y1 = 0;
+  const float det = A * C - B * B;
+  if (opacity >= rp.alpha_threshold && det > 0.f) {
+    const float qop = 2.f * logf(opacity / rp.alpha_threshold) * 1.0001f + 1e-4f;
+    const float qmax = fminf(rp.q_max * 1.00001f, qop);
+    const float hx = sqrtf(qmax * C / det) + 1e-3f, hy = sqrtf(qmax * A / det) + 1e-3f;
+    const float lo = -32768.f, hi = 32767.f;
+    x0 = (int)fminf(fmaxf(ceilf(u - hx - 0.5f), lo), hi);
+    x1 = (int)fminf(fmaxf(floorf(u + hx - 0.5f), lo), hi);
+    y0 = (int)fminf(fmaxf(ceilf(v - hy - 0.5f), lo), hi);
+    y1 = (int)fminf(fmaxf(floorf(v + hy - 0.5f), lo), hi);
+  }
+  return make_float2(__uint_as_float(((uint32_t)x0 & 0xFFFFu) | ((uint32_t)x1 << 16)),
+                     __uint_as_float(((uint32_t)y0 & 0xFFFFu) | ((uint32_t)y1 << 16)));
+}
+
 // sigma = sqrt(eig(cov)) of a projected splat from its conic: cov = conic^-1 = [C -B; -B A] / det(conic).
 // One definition (rounding pinned) for every kernel that reports points.screen_scale.
 __device__ __forceinline__ float2 gsr_screen_scale(float A, float B, float C) {
@@ -337,7 +359,8 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
   if (valid) {
     float* d = s_out + tid * OP;
     d[0] = o.u; d[1] = o.v; d[2] = o.A; d[3] = o.B; d[4] = o.C; d[5] = o.opacity; d[6] = gsr_qlim(o.opacity, rp);
-    d[7] = col[0]; d[8] = col[1]; d[9] = col[2]; d[10] = o.depth; d[11] = log2f(o.opacity); d[12] = 0.f; d[13] = 0.f;
+    const float2 bb = gsr_pixel_bbox(o.u, o.v, o.A, o.B, o.C, o.opacity, rp);
+    d[7] = col[0]; d[8] = col[1]; d[9] = col[2]; d[10] = o.depth; d[11] = log2f(o.opacity); d[12] = bb.x; d[13] = bb.y;
     d[14] = 0.f; d[15] = 0.f;
     if (JAC) {
 #pragma unroll
@@ -367,7 +390,8 @@ __global__ __launch_bounds__(256) void project_sh_fwd_kernel(
   r[0] = make_float4(o.u, o.v, o.A, o.B);
   r[1] = make_float4(o.C, o.opacity, gsr_qlim(o.opacity, rp), col[0]);
   r[2] = make_float4(col[1], col[2], o.depth, log2f(o.opacity));
-  r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float2 bb = gsr_pixel_bbox(o.u, o.v, o.A, o.B, o.C, o.opacity, rp);
+  r[3] = make_float4(bb.x, bb.y, 0.f, 0.f);
   *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(o.A, o.B, o.C);
   if (depth_keys) depth_keys[m] = gsr_depth_key(o.depth, key_bias, key_max);
   if (JAC) {
@@ -394,7 +418,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
   r[0] = make_float4(uv.x, uv.y, ab.x, ab.y);
   r[1] = make_float4(co.x, co.y, gsr_qlim(co.y, rp), f0);
   r[2] = make_float4(f1, f2, depth[m], log2f(co.y));
-  r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float2 bb = gsr_pixel_bbox(uv.x, uv.y, ab.x, ab.y, co.x, co.y, rp);
+  r[3] = make_float4(bb.x, bb.y, 0.f, 0.f);
   *reinterpret_cast<float2*>(sscale + 2 * m) = gsr_screen_scale(ab.x, ab.y, co.x);
 }
 

@@ -117,6 +117,19 @@ __device__ __forceinline__ Splat load_splat_packed(const float* __restrict__ rec
   return s;
 }
 
+// The backward walk's row: with GSR_K7_XFLEX also the x-extent of the splat's pixel box (row word 12).
+struct SplatB : Splat { uint32_t bx; };
+template <int C>
+__device__ __forceinline__ SplatB load_splat_bwd(const float* __restrict__ rec, uint32_t packed) {
+  SplatB s;
+  static_cast<Splat&>(s) = load_splat_packed<C, true>(rec, packed);
+  s.bx = 0u;
+#if GSR_K7_XFLEX
+  s.bx = __float_as_uint(rec[(size_t)GSR_ROW_FLOATS * (packed & 0x3FFFFFFFu) + 12]);
+#endif
+  return s;
+}
+
 // i is wave-uniform: the index load and the three 16-byte record loads become scalar-cache loads.
 template <int C, bool DEPTH = false>
 __device__ __forceinline__ Splat load_splat(const float* __restrict__ rec, const uint32_t* __restrict__ sorted_rank,
@@ -594,6 +607,9 @@ __global__ __launch_bounds__(64) void seg_combine_kernel(int W, int H, int tiles
 #ifndef GSR_K7_SEG_FIRST
 #define GSR_K7_SEG_FIRST 1
 #endif
+#ifndef GSR_K7_XFLEX             // narrow footprints: one 8-pixel-wide window per tile half instead of the packed half (see the walk)
+#define GSR_K7_XFLEX 0
+#endif
 #ifndef GSR_K7_ADDTID            // per-pair sums parked with ds_write_addtid_b32 (see the reduction)
 #define GSR_K7_ADDTID 1
 #endif
@@ -660,6 +676,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
   const int px0 = tx * 16 + (lane & 7), py0 = ty * 16 + (lane >> 3);
   const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f;
   const uint32_t start = tile_range[2 * tile];
+#if GSR_K7_XFLEX
+  const int lx8 = lane & 7, tile_px0 = tx * 16;
+#endif
 
   // per pixel (packed over the two sides of a half): T behind the current splat, g = dL/dC,
   // ga = g . (colour accumulated behind the current splat)
@@ -724,10 +743,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
     uint64_t flags = __ballot(pv > 0.f);
     if (flags == 0ull) continue;
     int j = 63 - __builtin_clzll(flags);
-    Splat nxt = load_splat_packed<C, true>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+    SplatB nxt = load_splat_bwd<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
     uint32_t inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
     while (true) {
-      const Splat s = nxt;
+      const SplatB s = nxt;
       const uint32_t inst_j = inst_nxt;
       const int pos = cbase + j;
       flags &= ~(1ull << j);
@@ -736,12 +755,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
       // prefetch the next contributing pair -- unconditionally (the chunk's last pair re-reads its own row), so that
       // `nxt` is always a fresh value: no copy of the row from "next" to "current" registers per pair
       j = more ? 63 - __builtin_clzll(flags) : j;
-      nxt = load_splat_packed<C, true>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+      nxt = load_splat_bwd<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
       inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
 #else
       if (more) {                                             // prefetch the next contributing pair
         j = 63 - __builtin_clzll(flags);
-        nxt = load_splat_packed<C, true>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
+        nxt = load_splat_bwd<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
         inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
       }
 #endif
@@ -753,10 +772,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
       // dopacity = m0 / opacity (m0 = sum GdG, the zeroth moment).
       v2f mx2 = GSR_V2(0.f), my2 = mx2, mxx2 = mx2, mxy2 = mx2, myy2 = mx2, dop2 = mx2, prune2 = mx2, split2 = mx2;
       v2f df2[3] = {mx2, mx2, mx2};
+#if GSR_K7_XFLEX
+      // A footprint at most 8 pixels wide inside this tile (wave-uniform, from the row's pixel box) is evaluated on ONE
+      // 8-wide window per tile half instead of the half's 16 columns: lane (lx, ly) takes the column of [a, a + 8)
+      // congruent to lx -- its left-quadrant pixel where lx >= a, its right-quadrant one otherwise -- in plain fp32, the
+      // pixel's state picked out of (and put back into) the halves of the packed register pairs by a per-lane select.
+      const int bx0 = max((int)(int16_t)(s.bx & 0xFFFFu) - tile_px0, 0), bx1 = min(((int)s.bx >> 16) - tile_px0, 15);
+      const bool narrow = bx1 - bx0 < 8;
+      const int xa = min(bx0, 8);
+      const bool sel = lx8 < xa;                                 // this lane's pixel of the window is its right-quadrant one
+      const float dxs = (sel ? fx0 + 8.f : fx0) - s.u;
+#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (!(s.halves & (1u << h))) continue;                            // scalar test: support misses this half
         const float dy = (h ? fy0 + 8.f : fy0) - s.v;
+#if GSR_K7_XFLEX
+        if (narrow) {
+#pragma clang fp contract(off)
+          const float T = sel ? T2[h].y : T2[h].x, gaf = sel ? ga2[h].y : ga2[h].x;
+          const float g0 = sel ? g2[h][0].y : g2[h][0].x, g1 = sel ? g2[h][1].y : g2[h][1].x, g2f = sel ? g2[h][2].y : g2[h][2].x;
+          const int lastv = sel ? lastc[2 * h + 1] : lastc[2 * h];
+          // q, t = conic d exactly as eval_q2 / eval_qt form them, for one pixel
+          const float bdy = s.B * dy, cdy = s.C * dy;
+          const float txf = __builtin_fmaf(dxs, s.A, bdy), tyf = __builtin_fmaf(dxs, s.B, cdy);
+          const float qf = __builtin_fmaf(dxs * s.A, dxs, __builtin_fmaf((s.B + s.B) * dy, dxs, cdy * dy));
+          const bool hit = pos < lastv && qf <= s.qlim;
+          if (__ballot(hit) != 0ull) {
+            const float a_raw = __builtin_amdgcn_exp2f(__builtin_fmaf(qf, -0.72134752044448170368f, s.l2op));
+            float alpha = __builtin_amdgcn_fmed3f(a_raw, 0.f, rp.clamp_max_alpha);
+            alpha = hit ? alpha : 0.f;
+            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);          // rcp(1) == 1 exactly
+            const float Tb = T * inv;
+            const float w = alpha * Tb;
+            float gc = g0 * s.f0;
+            if (C > 1) gc = __builtin_fmaf(g1, s.f1, gc);
+            if (C > 2) gc = __builtin_fmaf(g2f, s.f2, gc);
+            df2[0].x = __builtin_fmaf(w, g0, df2[0].x);
+            if (C > 1) df2[1].x = __builtin_fmaf(w, g1, df2[1].x);
+            if (C > 2) df2[2].x = __builtin_fmaf(w, g2f, df2[2].x);
+            const float dLda = Tb * gc - gaf * inv;
+            const float gan = __builtin_fmaf(gc, w, gaf);
+            T2[h] = sel ? (v2f){T2[h].x, Tb} : (v2f){Tb, T2[h].y};
+            ga2[h] = sel ? (v2f){ga2[h].x, gan} : (v2f){gan, ga2[h].y};
+            prune2.x = __builtin_fmaf(__builtin_fabsf(dLda), alpha, prune2.x);
+            float GdG = a_raw * dLda;
+            GdG = (hit && a_raw <= rp.clamp_max_alpha) ? GdG : 0.f;
+            dop2.x += GdG;
+            const float px_ = GdG * dxs, py_ = GdG * dy;
+            mx2.x += px_;
+            my2.x += py_;
+            mxx2.x = __builtin_fmaf(px_, dxs, mxx2.x);
+            mxy2.x = __builtin_fmaf(px_, dy, mxy2.x);
+            myy2.x = __builtin_fmaf(py_, dy, myy2.x);
+            const float nn = __builtin_fmaf(tyf, tyf, txf * txf);
+            split2.x = __builtin_fmaf(__builtin_fabsf(GdG), __builtin_amdgcn_sqrtf(nn), split2.x);
+          }
+          continue;
+        }
+#endif
         v2f q, tx_, ty_;
         eval_qt(dx2, dy, s.A, s.B, s.C, q, tx_, ty_);
         const bool hit0 = pos < lastc[2 * h] && q.x <= s.qlim;       // the forward walk's test (see fwd_walk)

@@ -169,12 +169,62 @@ def cpu_baseline(g, cam, cfg, budget_s: float = 25.0, chunk_tiles: int = 1024):
                       f"full pass {est:.1f}s"))
 
 
+def measure_scale_workload(name: str, dev, steps: int = 10, warm: int = 12):
+  """One-GPU, one-camera step of the workload the multi-GPU runs use (c3): the baseline a scaling curve over
+  ``bench.py --gpus N`` needs (those runs render camera k of the same scene on GPU k; per-GPU work is this step)."""
+  import splat_trainer_amd as sta
+  from splat_trainer_amd.controller_math import PointState
+  from splat_trainer_amd.distributed import CameraShardedStep
+  g, cams, w = make_workload(name, 1)
+  cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True, blur_cov=0.3, antialias=False)
+  params = [t.to(dev).requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
+  scene = sta.Gaussians3D(position=params[0], rotation=params[2], log_scaling=params[1], alpha_logit=params[3], feature=params[4])
+  cam = cams[0].to(dev)
+  target = torch.full((w["h"], w["w"], 3), 0.5, device=dev)
+  dp = CameraShardedStep(params, 1, 0)
+  state = PointState.new_zeros(params[0].shape[0], dev)
+  last = {}
+
+  def render_backward(j, c, grad_out, collector):
+    with torch.enable_grad():
+      r = sta.render_gaussians(scene, c, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
+      sta.clamped_mse_loss(r.image, target).backward()
+    last["r"] = r
+    return r
+
+  for _ in range(warm):
+    dp.run([cam], render_backward, point_state=state)
+  marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  marks[0].record()
+  for i in range(steps):
+    dp.run([cam], render_backward, point_state=state)
+    marks[i + 1].record()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+  N = params[0].shape[0]
+  return {"workload": f"{name}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, camera 0 of the 8-camera "
+                      f"orbit, MSE loss (what one rank of `bench.py --gpus N` does per step, without the exchange)",
+          "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "ms_per_step_median": per[len(per) // 2],
+          "value": N * steps / elapsed, "unit": "Gaussians/s", "tile_overlaps": int(last["r"].num_overlaps),
+          "visible": int(last["r"].points.idx.shape[0])}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=20)
   ap.add_argument("--warmup", type=int, default=5)
-  ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+  ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                  help="default: c2 on one GPU (BASELINE configs[1], the configuration the metric is quoted on); c3 at "
+                       "--gpus > 1 (the 3M-Gaussian scene north_star quotes the scaling target on, camera k on GPU k)")
+  ap.add_argument("--loss", default="mse", choices=["mse", "ref"],
+                  help="mse (default): clamped MSE against a constant image (SURVEY.md section 8d); ref: the reference's loss "
+                       "mix, L1 + MSE + 4-level fused_ssim on 2x average-pooled pyramids (trainer.py:448-488, loss.reference_loss)")
+  ap.add_argument("--no-scale-workload", action="store_true",
+                  help="skip the nested one-GPU measurement of the multi-GPU workload (c3) that the N = 1 line carries")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--form", default="one_call", choices=["one_call", "three_call"],
                   help="one_call (default): render_gaussians(use_sh=True), the fused node behind the native frame driver; "
@@ -198,6 +248,8 @@ def main():
 
   if args.gpus < 1:
     raise SystemExit("--gpus must be >= 1")
+  if args.workload is None:
+    args.workload = "c2" if args.gpus == 1 else "c3"
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     # Started without a launcher: start the N ranks ourselves (one process per GPU over RCCL) as a CHILD process, before
     # anything in this process has touched the GPU (device_count() does not initialise it), and exit with its code.
@@ -253,6 +305,10 @@ def main():
   bucket = dp.bucket
   batch = [c.to(dev) for c in cams[:max(world, 1)]]                       # one camera per rank per step
   target_image = torch.full((w["h"], w["w"], 3), 0.5, device=dev)
+  if args.loss == "ref":       # SSIM against a constant image is degenerate (zero variance): a smooth, seeded pattern instead
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, w["h"], device=dev), torch.linspace(0, 1, w["w"], device=dev), indexing="ij")
+    target_image = (0.5 + 0.25 * torch.stack([torch.sin(9 * xx + 3 * yy), torch.cos(7 * yy - 2 * xx), torch.sin(5 * (xx + yy))],
+                                             dim=-1)).contiguous()
   scene = sta.Gaussians3D(position=position, rotation=rotation, log_scaling=log_scaling, alpha_logit=alpha_logit,
                           feature=feature)
   point_state = PointState.new_zeros(N, dev)                               # the controller's state (point_state.py:22-32)
@@ -268,7 +324,10 @@ def main():
         r = sta.render_projected(idx, g2d, feats, depth, cam, cfg, _depth_order=prefetch.get("depth_order"))
       else:
         r = sta.render_gaussians(scene, cam, cfg, use_sh=True, grad_out=grad_out, sh_collector=collector)
-      loss = sta.clamped_mse_loss(r.image, target_image)      # = F.mse_loss(image.clamp(0, 1), target), trainer.py:472-475
+      if args.loss == "ref":
+        loss = sta.reference_loss(r.image, target_image)        # trainer.py:448-488: L1 + MSE + multi-scale SSIM
+      else:
+        loss = sta.clamped_mse_loss(r.image, target_image)      # = F.mse_loss(image.clamp(0, 1), target), trainer.py:472-475
       loss.backward()
     last["r"] = r
     return r
@@ -426,7 +485,8 @@ def main():
         "ms_first_step": step_trace[0],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: scene {w['scene']}, {N} Gaussians, {w['w']}x{w['h']}, SH deg {w['sh']}, "
-                               f"1 camera per GPU per step, MSE loss, compute_visibility+point_heuristic on"
+                               f"1 camera per GPU per step, {'reference loss mix (L1 + MSE + 4-level SSIM)' if args.loss == 'ref' else 'MSE loss'}, "
+                               f"compute_visibility+point_heuristic on"
                                + (", three-call form" if args.form == "three_call" else ""),
                    "gaussians": N, "visible": M, "tile_overlaps": O, "pixels": P, "cameras_per_step": cameras_per_step,
                    "parallelism": ("dp1 (one GPU: gradients accumulate in place, no collective)" if world == 1 else
@@ -437,12 +497,18 @@ def main():
                                    f"dp{world} (camera-sharded, fused {args.collective} of {bucket.flat.numel() * 4 / 1e6:.0f} MB grads)"),
                    "parity": "parity unpinned by the reference (its rasterizer is an absent third-party package); "
                              "HIP vs this build's fp64 oracle is asserted by tests/ (-m gpu), observed errors in "
-                             "profiles/r03_parity_observed.txt"},
+                             "profiles/r04_parity_observed.txt"},
         "roofline": k7,
     }
     if check is not None:
       out["config"]["collective_check_rel_err"] = check
       out["config"]["statistics_check_bit_identical"] = stats_check
+    if world == 1 and args.workload == "c2" and not args.no_scale_workload:
+      # the multi-GPU runs default to c3 (camera k on GPU k): its one-GPU, one-camera step, so a scaling curve has its baseline
+      try:
+        out["scale_workload"] = measure_scale_workload("c3", dev)
+      except Exception as e:   # noqa: BLE001 -- never take the headline down with it
+        out["scale_workload"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
       try:
         out["cpu_baseline"] = cpu_baseline(g, cams[0], cfg)

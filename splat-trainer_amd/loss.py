@@ -122,3 +122,26 @@ def clamped_mse_loss(image: torch.Tensor, target: torch.Tensor, clamp=(0.0, 1.0)
 def clamped_l1_loss(image: torch.Tensor, target: torch.Tensor, clamp=(0.0, 1.0)) -> torch.Tensor:
   """``F.l1_loss(image.clamp(*clamp), target)`` (trainer.py:470-471), fused the same way."""
   return _pixel_loss(image, target, 1, clamp)
+
+
+def reference_loss(image: torch.Tensor, target: torch.Tensor, l1_weight: float = 0.0, mse_weight: float = 10.0,
+                   ssim_weight: float = 1.0, ssim_levels: int = 4, clamp=(0.0, 1.0)) -> torch.Tensor:
+  """The reference's per-camera loss mix, ``Trainer.compute_losses`` without ``reg_loss`` (trainer.py:448-488): L1 and
+  MSE of the image against the target, and the multi-scale SSIM loss -- ``fused_ssim(padding="valid")`` on the
+  channels_last view of the (H, W, 3) image and on ``ssim_levels - 1`` successive 2 x 2 average poolings of it, the mean
+  of the levels' ``1 - ssim`` -- each times its weight (defaults: config/trainer/default.yaml:52-54 for the weights,
+  trainer/config.py:70 for the levels; all three terms are formed whatever their weight, as the reference does).
+  ``image`` is the UNclamped rendering; the reference receives it clamped from ``MLPScene.render`` (mlp_scene.py:421-423),
+  which ``clamp`` restates.  The reference's ``.item()`` calls (logged metrics) are not part of the arithmetic."""
+  import torch.nn.functional as F
+  l1 = clamped_l1_loss(image, target, clamp)
+  mse = clamped_mse_loss(image, target, clamp)
+  img = image.clamp(*clamp) if clamp is not None else image
+  ref = target.unsqueeze(0).permute(0, 3, 1, 2)
+  pred = img.unsqueeze(0).permute(0, 3, 1, 2)
+  loss = 1.0 - fused_ssim(pred, ref, padding="valid")
+  for _ in range(1, ssim_levels):
+    pred = F.avg_pool2d(pred, kernel_size=2, stride=2)
+    ref = F.avg_pool2d(ref, kernel_size=2, stride=2)
+    loss = loss + (1.0 - fused_ssim(pred, ref, padding="valid"))
+  return l1 * l1_weight + mse * mse_weight + (loss / ssim_levels) * ssim_weight

@@ -140,3 +140,29 @@ def test_fused_pixel_losses_match_torch(shape):
     assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-12)
   c = x0.clone().requires_grad_(True)
   assert torch.allclose(sta.clamped_mse_loss(c, t, clamp=None), F.mse_loss(x0, t), rtol=2e-6)
+
+
+@pytest.mark.gpu
+def test_reference_loss_mix_matches_the_torch_expression():
+  """loss.reference_loss = Trainer.compute_losses without reg_loss (trainer.py:448-488): L1 + MSE + multi-scale SSIM
+  with the reference's weights, against the same expression in fp64 torch + the SSIM oracle; value within 2e-6, gradient
+  within 1e-4 of its largest entry (pixels outside [0, 1] included: the clamp passes no gradient there)."""
+  import splat_trainer_amd as sta
+  torch.manual_seed(9)
+  H, W = 270, 480
+  ref = torch.rand(H, W, 3)
+  pred = ref + 0.1 * torch.randn(H, W, 3) + 0.05                       # some pixels leave [0, 1]
+  for weights in (dict(l1_weight=0.0, mse_weight=10.0, ssim_weight=1.0, ssim_levels=4),
+                  dict(l1_weight=1.0, mse_weight=0.5, ssim_weight=0.2, ssim_levels=3)):
+    pd = pred.clone().cuda().requires_grad_(True)
+    got = sta.reference_loss(pd, ref.cuda(), **weights)
+    got.backward()
+    po = pred.clone().double().requires_grad_(True)
+    img = po.clamp(0, 1)
+    ssim_l, _ = ssim_oracle.multiscale_ssim_loss(img, ref.double(), levels=weights["ssim_levels"])
+    want = (F.l1_loss(img, ref.double()) * weights["l1_weight"] + F.mse_loss(img, ref.double()) * weights["mse_weight"] +
+            ssim_l * weights["ssim_weight"])
+    want.backward()
+    assert abs(got.item() - want.item()) < 2e-6 * max(1.0, abs(want.item())), (got.item(), want.item())
+    err = (pd.grad.cpu().double() - po.grad).abs().max().item() / po.grad.abs().max().item()
+    assert err < 1e-4, err

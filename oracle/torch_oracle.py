@@ -220,10 +220,29 @@ class RasterOutputs:
   prune_cost: Optional[torch.Tensor] = None
   split_score: Optional[torch.Tensor] = None
   num_overlaps: int = 0
+  pixel_margin: Optional[torch.Tensor] = None   # (H, W)  smallest decision margin along the pixel's list (want_margins)
+  splat_margin: Optional[torch.Tensor] = None   # (M,)    smallest pixel margin among the pixels the splat touches
+  splat_own_margin: Optional[torch.Tensor] = None   # (M,) smallest margin of the splat's OWN decisions (it is the candidate)
+
+
+# A pixel's result is a sum of discrete decisions, one per splat of its list: inside the support and above the alpha
+# threshold (q <= qlim = min(q_max, 2 ln(opacity / threshold))), transmittance still above T_eps, alpha below the clamp
+# (the clamp only switches the gradient through G), and which of two splats comes first.  An fp32 implementation within
+# rounding of a boundary may decide the other way and move the pixel -- and the sums of every splat composited there -- by
+# one minimal contribution.  ``want_margins`` reports how close the fp64 walk came to each boundary IN UNITS OF WHAT ONE
+# fp32 ULP OF ROUNDING IN THE OPERANDS MOVES THE TESTED QUANTITY BY:
+#   q vs qlim   one ulp in the pixel offsets (coordinates of magnitude |pixel|), the conic terms and qlim:
+#               dq1 = eps32 (2 (|t_x| |x| + |t_y| |y|) + |A| dx^2 + 2 |B dx dy| + |C| dy^2 + qlim),  t = conic d
+#   T vs T_eps  a product of j + 1 rounded factors:  dT1 = eps32 (j + 2) T
+#   alpha_raw vs the clamp:  da1 = alpha_raw (eps32 + dq1 / 2)
+#   depth order of two list neighbours that both contribute: relative gap / eps32
+# so that a parity test can demand that every entry outside its tolerance sits within a STATED number of ulps of a boundary
+# (tests/helpers.py: compare_explained).
+MARGIN_EPS32 = 2.0 ** -23
 
 
 def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None, want_median=False,
-                     pix_valid=None):
+                     pix_valid=None, want_margins=False):
   """idx (B,L) splat ids (padded), valid (B,L), pix (B,P,2) pixel centres, pix_valid (B,P) inside-image mask.
 
   Returns image (B,P,C), final_T (B,P), w (B,P,L) weights, plus -- when dL_dimage (B,P,C) is given --
@@ -275,12 +294,48 @@ def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None,
       gy = dL_dG * G * (Bc * dx + Cc * dy)
       split = torch.sqrt(gx * gx + gy * gy)
       extra = (prune, split)
+  margins = None
+  if want_margins:
+    with torch.no_grad():
+      inf = torch.full_like(q, float("inf"))
+      e32 = MARGIN_EPS32
+      qlim = torch.minimum(torch.full_like(op, config.gaussian_scale ** 2),
+                           2.0 * torch.log((op / config.alpha_threshold).clamp_min(1e-300)))
+      listed = valid[:, None, :] & (qlim > 0)
+      if pix_valid is not None:
+        listed = listed & pix_valid[:, :, None]
+      inside = q <= qlim
+      near_live = T_excl >= config.transmittance_eps * (1.0 - 1e-3)
+      tx, ty = (A * dx + Bc * dy).abs(), (Bc * dx + Cc * dy).abs()
+      xs, ys = pix[:, :, None, 0].abs().clamp_min(1.0), pix[:, :, None, 1].abs().clamp_min(1.0)
+      dq1 = e32 * (2.0 * (tx * xs + ty * ys) + A.abs() * dx * dx + 2.0 * (Bc * dx * dy).abs() + Cc.abs() * dy * dy + qlim.abs())
+      m = torch.where(listed & near_live, (q - qlim).abs() / dq1.clamp_min(1e-300), inf)
+      steps = torch.arange(q.shape[2], dtype=q.dtype, device=q.device)[None, None, :] + 2.0
+      dT1 = e32 * steps * T_excl.clamp_min(config.transmittance_eps * 0.5)
+      m = torch.minimum(m, torch.where(listed & inside, (T_excl - config.transmittance_eps).abs() / dT1, inf))
+      da1 = a_raw * (e32 + 0.5 * dq1)
+      m = torch.minimum(m, torch.where(listed & inside & live, (a_raw - config.clamp_max_alpha).abs() / da1.clamp_min(1e-300), inf))
+      # list neighbours that both contribute and whose depths an fp32 key cannot tell apart
+      d = depth.reshape(-1)[idx]                                          # (B, L)
+      gap = ((d[:, 1:] - d[:, :-1]).abs() / d[:, 1:].abs().clamp_min(1e-300)) / e32
+      both = (w[:, :, 1:] > 0) & (w[:, :, :-1] > 0)
+      mg = torch.where(both, gap[:, None, :].expand_as(both), inf[:, :, 1:])
+      m[:, :, 1:] = torch.minimum(m[:, :, 1:], mg)
+      m[:, :, :-1] = torch.minimum(m[:, :, :-1], mg)
+      mpx = m.min(dim=2).values                                           # (B, P)
+      # a splat is touched by a pixel's flip when it contributes there (everything behind the flipped splat moves with T)
+      # or is itself the candidate (its own entry is the close one)
+      sm = torch.minimum(torch.where(w > 0, mpx[:, :, None].expand_as(m), inf), m).min(dim=1).values   # (B, L)
+      margins = (mpx, sm, m.min(dim=1).values)
+  if want_margins:
+    return image, final_T, w, median, extra, margins
   return image, final_T, w, median, extra
 
 
 def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image_size, config,
               dL_dimage: Optional[torch.Tensor] = None, want_median: bool = False,
-              tile_batch: int = 64, tiles: Optional[torch.Tensor] = None, lists=None) -> RasterOutputs:
+              tile_batch: int = 64, tiles: Optional[torch.Tensor] = None, lists=None,
+              want_margins: bool = False) -> RasterOutputs:
   """Tile-batched compositing of projected splats.  Differentiable wrt g2d and feats (autograd).
 
   ``dL_dimage`` (H,W,C): when given, also returns the per-point heuristics prune_cost / split_score
@@ -300,6 +355,9 @@ def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image
   vis = torch.zeros(M, dtype=dtype, device=dev)
   prune = torch.zeros(M, dtype=dtype, device=dev) if dL_dimage is not None else None
   split = torch.zeros(M, dtype=dtype, device=dev) if dL_dimage is not None else None
+  pmargin = torch.full((th * ts, tw * ts), float("inf"), dtype=dtype, device=dev) if want_margins else None
+  smargin = torch.full((M,), float("inf"), dtype=dtype, device=dev) if want_margins else None
+  omargin = torch.full((M,), float("inf"), dtype=dtype, device=dev) if want_margins else None
   gpad = None
   if dL_dimage is not None:
     gpad = torch.zeros(th * ts, tw * ts, C, dtype=dtype, device=dev)
@@ -325,10 +383,18 @@ def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image
     px = tx[:, None] * ts + ox[None, :]
     pix = torch.stack([px.to(dtype) + 0.5, py.to(dtype) + 0.5], dim=-1)
     gB = gpad[py, px] if gpad is not None else None
-    img, fT, w, med, extra = _composite_batch(g2d, feats, depth, idx, valid, pix, config, gB, want_median,
-                                              pix_valid=(px < W) & (py < H))
+    res = _composite_batch(g2d, feats, depth, idx, valid, pix, config, gB, want_median,
+                           pix_valid=(px < W) & (py < H), want_margins=want_margins)
+    img, fT, w, med, extra = res[:5]
     image_parts.append((py, px, img))
     with torch.no_grad():
+      if want_margins:
+        pmargin[py, px] = res[5][0]
+        import warnings
+        with warnings.catch_warnings():
+          warnings.simplefilter("ignore")                   # (index_reduce_ is flagged "beta")
+          smargin.index_reduce_(0, idx.reshape(-1), res[5][1].reshape(-1), "amin", include_self=True)
+          omargin.index_reduce_(0, idx.reshape(-1), res[5][2].reshape(-1), "amin", include_self=True)
       final_T[py, px] = fT
       if want_median:
         median[py, px] = med
@@ -345,7 +411,9 @@ def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image
   return RasterOutputs(image=image[:H, :W], final_T=final_T[:H, :W], visibility=vis,
                        median_depth=median[:H, :W] if want_median else None,
                        prune_cost=prune, split_score=split,
-                       num_overlaps=int(counts.sum().item()))
+                       num_overlaps=int(counts.sum().item()),
+                       pixel_margin=pmargin[:H, :W] if want_margins else None, splat_margin=smargin,
+                       splat_own_margin=omargin)
 
 
 def rasterize_dense(g2d, depth, feats, image_size, config, dL_dimage=None, want_median=False) -> RasterOutputs:

@@ -242,6 +242,17 @@ __global__ __launch_bounds__(RS_THREADS) void rs_digit_scan_kernel(const uint32_
 // (Round 2's form ranked 256 elements per round across the four waves: three block barriers and ~26 LDS operations per
 // element, most of them on bins the round never touched; this one has four barriers per BLOCK and ~7 LDS operations per
 // element.)
+// GSR_RS_NEXT_HIST (experiment): price of forming the NEXT pass's block histograms while this pass
+// scatters -- one integer atomic per element on hist'[next digit][destination block] (a block's elements go to ~BINS
+// destination runs of ~TILE / BINS elements each, so (destination block, next digit) pairs hardly repeat inside a block:
+// nothing to pre-aggregate).  The adds go to a dummy table; the sort's results are untouched.  See profiles/r04_sorts.txt.
+#ifndef GSR_RS_NEXT_HIST
+#define GSR_RS_NEXT_HIST 0
+#endif
+#if GSR_RS_NEXT_HIST
+__device__ uint32_t g_rs_dummy_hist[512 * 4096];
+#endif
+
 template <bool TWO, int ROUNDS, int BITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,   // null -> iota
@@ -348,6 +359,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t* 
     keys_out[dst] = k;
     vals_out[dst] = s_val[e];
     if (TWO) vals2_out[dst] = s_val2[e];
+#if GSR_RS_NEXT_HIST
+    atomicAdd(&g_rs_dummy_hist[(((k >> (shift + BITS)) & (BINS - 1)) * 4096u + min(dst / (uint32_t)TILE, 4095u))], 1u);
+#endif
   }
 }
 

@@ -73,6 +73,85 @@ def clean_or_isolated_flip(label: str, key: str, a: torch.Tensor, b: torch.Tenso
   return frac > 0
 
 
+# ---- explained flips (round 4).  The oracle reports, per pixel, how close its fp64 walk came to a discrete boundary, in
+# units of what one fp32 ulp of rounding in the operands moves the tested quantity by (oracle/torch_oracle.py:
+# want_margins), and per splat the smallest such margin among the pixels the splat touches.  The rule: an entry outside
+# the tolerance must be EXPLAINED -- an image / final-T entry lies on a pixel within FLIP_ULPS of a boundary, a per-point
+# or gradient entry belongs to a splat that touches such a pixel -- and small (FLIP_SIZE of the tensor's largest
+# magnitude: a flip moves a pixel by one minimal contribution).  An indexing bug (a wrong half mask, a tile edge) lands on
+# arbitrary pixels: the share of pixels within FLIP_ULPS of a boundary is logged next to every comparison.
+# Gradient rows have a second, continuous explanation: the 2-D conic of a very elongated splat is ill-conditioned in fp32
+# (det = A C - B^2 cancels; observed: condition 1186, sigma 21.6 x 0.63 px at depth 0.21 -> 0.75 % error in one gradient
+# component that happens to be the tensor's largest), so a gradient row may be off by COND_GAIN x (condition number of the
+# splat's conic) relative to the ROW's own largest magnitude.  Both classes are counted and logged separately.
+FLIP_ULPS = 8.0             # observed (profiles/r04_parity_observed.txt): flipped pixels sit within 2.5, flipped splats within 2.7
+COND_GAIN = 1e-5            # = 84 eps32 per unit of condition number; observed 6.3e-6 (seed 46) and 3.1e-6 (seed 73)
+EXPLAINED_LOG = []          # (label, key, entries above tol, unexplained, largest margin among the flips, share of units flagged,
+                            #  conditioned rows, rows whose splat is only BEHIND a flip, share of splats that are candidates themselves)
+
+
+def conic_condition(g2d: torch.Tensor) -> torch.Tensor:
+  A, B, C = g2d[:, 2].double(), g2d[:, 3].double(), g2d[:, 4].double()
+  half, det = 0.5 * (A + C), (A * C - B * B).clamp_min(1e-300)
+  l1 = half + (half * half - det).clamp_min(0).sqrt()
+  return l1 * l1 / det                                        # lambda_max / lambda_min, with lambda_min = det / lambda_max
+
+
+def compare_explained(label: str, hip: dict, orc: dict, tol: float = 1e-4, keys=None, ulps: float = FLIP_ULPS,
+                      size: float = FLIP_SIZE) -> int:
+  """Every entry of every tensor within ``tol`` of the oracle (relative to the tensor's largest magnitude) or an explained
+  flip (above).  Returns the number of entries above ``tol`` (all explained, or the assertion fails)."""
+  keys = keys or (("image", "final_T") + POINT_KEYS + GRAD_KEYS)
+  pm = orc["pixel_margin"].double().cpu()
+  sm = orc["splat_margin"].double().cpu()
+  idx = orc["idx"].cpu()
+  assert torch.equal(hip["idx"].cpu(), idx)
+  flagged_px, flagged_sp = pm < ulps, sm < ulps
+  total = 0
+  for k in keys:
+    if k not in hip or hip[k] is None or orc.get(k) is None:
+      continue
+    a, b = hip[k].detach().double().cpu(), orc[k].detach().double().cpu()
+    worst, _ = observe(label, k, a, b, tol)
+    scale = max(b.abs().max().item(), 1e-30)
+    bad = ((a - b).abs() / scale) > tol
+    n_bad = int(bad.sum())
+    total += n_bad
+    conditioned = 0
+    if k in ("image", "final_T", "median"):
+      unit_bad = bad.reshape(pm.shape[0], pm.shape[1], -1).any(dim=2)
+      margins, flagged = pm, flagged_px
+    else:
+      rows = bad.reshape(bad.shape[0], -1).any(dim=1)
+      per_point = rows.shape[0] == sm.shape[0] and k not in GRAD_KEYS
+      if per_point:                                          # per visible point
+        unit_bad = rows
+      else:                                                  # per scene row: visible rows map through idx
+        assert not rows[torch.ones_like(rows).index_fill_(0, idx, False)].any(), (label, k, "error on a culled row")
+        unit_bad = rows[idx]
+      margins, flagged = sm, flagged_sp
+      if k in GRAD_KEYS and orc.get("g2d") is not None and unit_bad.any():
+        # rows of an ill-conditioned splat: error within COND_GAIN x condition of the row's own largest magnitude
+        cond = conic_condition(orc["g2d"].detach().cpu())
+        a2, b2 = a.reshape(a.shape[0], -1)[idx], b.reshape(b.shape[0], -1)[idx]
+        row_err = (a2 - b2).abs().max(dim=1).values / b2.abs().max(dim=1).values.clamp_min(1e-30)
+        by_cond = unit_bad & ~flagged & (row_err <= COND_GAIN * cond)
+        conditioned = int(by_cond.sum())
+        unit_bad = unit_bad & ~by_cond
+    unexplained = int((unit_bad & ~flagged).sum())
+    largest = float(margins[unit_bad].max()) if unit_bad.any() else 0.0
+    behind, own_share = 0, 0.0
+    if margins is sm and orc.get("splat_own_margin") is not None:
+      # the tighter statement: the splat's OWN decision is the close one; the rest are splats behind a flipped one
+      own = orc["splat_own_margin"].double().cpu() < ulps
+      behind = int((unit_bad & flagged & ~own).sum())
+      own_share = float(own.double().mean())
+    EXPLAINED_LOG.append((label, k, n_bad, unexplained, largest, float(flagged.double().mean()), conditioned, behind, own_share))
+    assert unexplained == 0, (label, k, "entries above tol on units no boundary explains", unexplained, largest)
+    assert worst < max(tol, size), (label, k, worst)
+  return total
+
+
 GRAD_KEYS = ("d_position", "d_log_scaling", "d_rotation", "d_alpha_logit", "d_feature")
 POINT_KEYS = ("visibility", "prune_cost", "split_score", "screen_scale", "depth")
 
@@ -125,8 +204,10 @@ def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=Fals
     feats = oracle.evaluate_sh_at(feat.detach(), pos.detach(), idx, -(R.t() @ T[:3, 3]))
   else:
     feats = feat.detach()[idx]
-  heur = oracle.rasterize(g2d.detach(), depth.detach(), feats, cam.image_size, config, dL_dimage=image.grad)
-  return dict(image=image.detach(), final_T=out.final_T, visibility=out.visibility, median=out.median_depth,
+  heur = oracle.rasterize(g2d.detach(), depth.detach(), feats, cam.image_size, config, dL_dimage=image.grad,
+                          want_margins=True)
+  return dict(pixel_margin=heur.pixel_margin, splat_margin=heur.splat_margin, splat_own_margin=heur.splat_own_margin,
+              image=image.detach(), final_T=out.final_T, visibility=out.visibility, median=out.median_depth,
               g2d=g2d.detach(), d_g2d=g2d.grad, depth=depth.detach(), screen_scale=sscale, idx=idx, loss=loss.detach(),
               d_position=pos.grad, d_log_scaling=ls.grad, d_rotation=rot.grad, d_alpha_logit=al.grad,
               d_feature=feat.grad, prune_cost=heur.prune_cost, split_score=heur.split_score,
@@ -158,6 +239,9 @@ def oracle_render_and_grads_chunked(g, cam, config, use_sh, target=0.5, dtype=to
   image = torch.zeros(H, W, C, dtype=dtype)
   final_T = torch.ones(H, W, dtype=dtype)
   vis, prune, split = (torch.zeros(M, dtype=dtype) for _ in range(3))
+  pmargin = torch.full((H, W), float("inf"), dtype=dtype)
+  smargin = torch.full((M,), float("inf"), dtype=dtype)
+  omargin = torch.full((M,), float("inf"), dtype=dtype)
   overlaps = 0
   for t0 in range(0, n_tiles, chunk_tiles):
     tiles = torch.arange(t0, min(t0 + chunk_tiles, n_tiles))
@@ -169,7 +253,10 @@ def oracle_render_and_grads_chunked(g, cam, config, use_sh, target=0.5, dtype=to
     loss.backward()
     with torch.no_grad():
       heur = oracle.rasterize(g2d_d.detach(), depth.detach(), feats_d.detach(), cam.image_size, config, tiles=tiles,
-                              lists=lists, dL_dimage=img.grad)
+                              lists=lists, dL_dimage=img.grad, want_margins=True)
+      pmargin = torch.minimum(pmargin, heur.pixel_margin)
+      smargin = torch.minimum(smargin, heur.splat_margin)
+      omargin = torch.minimum(omargin, heur.splat_own_margin)
       image += out.image.detach()
       final_T = torch.minimum(final_T, out.final_T)
       vis += out.visibility
@@ -177,7 +264,8 @@ def oracle_render_and_grads_chunked(g, cam, config, use_sh, target=0.5, dtype=to
       split += heur.split_score
     overlaps = out.num_overlaps
   torch.autograd.backward([g2d, feats], [g2d_d.grad, feats_d.grad])
-  return dict(image=image, final_T=final_T, visibility=vis, g2d=g2d.detach(), d_g2d=g2d_d.grad, depth=depth.detach(),
+  return dict(pixel_margin=pmargin, splat_margin=smargin, splat_own_margin=omargin,
+              image=image, final_T=final_T, visibility=vis, g2d=g2d.detach(), d_g2d=g2d_d.grad, depth=depth.detach(),
               screen_scale=sscale, idx=idx, d_position=pos.grad, d_log_scaling=ls.grad, d_rotation=rot.grad,
               d_alpha_logit=al.grad, d_feature=feat.grad, prune_cost=prune, split_score=split, num_overlaps=overlaps)
 

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 import splat_trainer_amd as sta
-from helpers import clean_or_isolated_flip, hip_render_and_grads, oracle_render_and_grads
+from helpers import clean_or_isolated_flip, compare_explained, hip_render_and_grads, oracle_render_and_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -69,11 +69,17 @@ def test_random_scene_matches_oracle_up_to_isolated_flips(seed):
   orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
   assert len(set(hip["idx"].tolist()) ^ set(orc["idx"].tolist())) == 0
   flipped = False
+  live = []
   for k in KEYS:
     if orc[k].abs().max() == 0:
       assert hip[k].abs().max() == 0, (seed, k)
       continue
+    live.append(k)
     flipped |= clean_or_isolated_flip(f"fuzz seed {seed}", k, hip[k], orc[k], 2e-4)
+  # the share / size rule above is the net for gross errors; what passes it must also be EXPLAINED: every entry above the
+  # tolerance on a pixel / a splat within FLIP_ULPS of a decision boundary of the oracle's own walk (median depth aside:
+  # its decision, T crossing one half, is not one of the walk's reported boundaries)
+  compare_explained(f"fuzz seed {seed} (explained)", hip, orc, 2e-4, keys=[k for k in live if k != "median"])
   FLIPPED[seed] = flipped
 
 

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import splat_trainer_amd as sta
-from helpers import compare_to_oracle, frac_above, hip_render_and_grads, observe, oracle_render_and_grads_chunked, oracle, oracle_render_and_grads, rel_err, small_scene
+from helpers import compare_explained, compare_to_oracle, frac_above, hip_render_and_grads, observe, oracle_render_and_grads_chunked, oracle, oracle_render_and_grads, rel_err, small_scene
 from splat_trainer_amd import synthetic
 from splat_trainer_amd.controller_math import PointState, find_split_prune_indexes
 
@@ -43,10 +43,10 @@ def test_config1_10k_256_matches_oracle():
   g, cam = synthetic.scene_a(10_000, 256, 256, sh_degree=0, seed=0)
   hip = hip_render_and_grads(g, cam, CFG, use_sh=True)
   orc = oracle_render_and_grads(g, cam, CFG, use_sh=True)
-  # 2.8e4 (tile, splat) pairs, 1e6 contributing (pixel, splat) pairs: an isolated boundary flip may show (observed in
-  # round 3: 2 of 196 608 image entries, 2.5e-4); allowances = the share / size rule of the full-size configs
-  compare_to_oracle("test_config1_10k_256_matches_oracle", hip, orc, TOL, pixel_flips=5e-5, point_flips=3e-4,
-                    worst_pixel=1e-2, worst_point=1e-2)
+  # 2.8e4 (tile, splat) pairs, 1e6 contributing (pixel, splat) pairs: a boundary flip may show (round 3: 2 of 196 608
+  # image entries, 2.5e-4) -- every entry above tol must be an EXPLAINED flip (helpers.compare_explained), and few
+  n_bad = compare_explained("test_config1_10k_256_matches_oracle", hip, orc, TOL)
+  assert n_bad <= 40, n_bad
   mse = ((hip["image"].cpu() - orc["image"]) ** 2).mean().item()
   assert mse < 1e-10                       # PSNR vs oracle > 100 dB
   assert abs(hip["num_overlaps"]) > 0
@@ -217,6 +217,8 @@ def test_config2_full_size_matches_oracle_everywhere():
   # largest 3.5e-3 (image) / 1.3e-3 (d_position) -- boundary flips; the bounds are ~2.5x those numbers
   compare_to_oracle("c2 full size 500k 1080p SH3", hip, orc, TOL, pixel_flips=1e-4, point_flips=1.2e-4,
                     worst_pixel=1e-2, worst_point=4e-3)
+  # ... and every one of those entries sits on a pixel / a splat within FLIP_ULPS of a decision boundary of the oracle's walk
+  compare_explained("c2 full size (explained flips)", hip, orc, TOL)
   mse = ((hip["image"].cpu().double() - orc["image"]) ** 2).mean().item()
   assert mse < 1e-10, mse                       # PSNR vs oracle > 100 dB (observed 3.0e-11 = 105 dB)
   hs, hp, hst = _masks_from(hip, n, int(1.1 * n))
@@ -233,21 +235,23 @@ def test_config2_full_size_matches_oracle_everywhere():
     assert diff.numel() <= 20, (name, diff.numel())
 
 
-def test_config3_full_size_sampled_tiles_match_oracle():
-  """BASELINE.json configs[2], one camera (3M Gaussians, 1080p, SH degree 3; ~800 pairs on every tile), against the fp64
+@pytest.mark.parametrize("n,w,h,ntiles,label", [(3_000_000, 1920, 1080, 384, "c3 full size 3M 1080p SH3"),
+                                                 (10_000_000, 3840, 2160, 128, "c5 full size 10M 4K SH3")])
+def test_config3_full_size_sampled_tiles_match_oracle(n, w, h, ntiles, label):
+  """BASELINE.json configs[2] and configs[4], one camera (3M Gaussians at 1080p / 10M at 4K, SH degree 3; ~800 / ~680
+  pairs on every tile), against the fp64
   oracle: the projection outputs of all 3M points; the depth ORDER (the HIP depths must be the oracle's fp64 depths
   rounded to fp32, bit for bit, so that the stable sort sees the same keys: at 3M splats neighbouring depths are one
   fp32 ulp apart); the composited image / final T of a fixed sample of 384 tiles; and -- for the loss restricted to those
   tiles -- ALL parameter gradients of all 3M points and the two backward heuristics (a loss that only looks at the
   sampled tiles has gradients the oracle can form from those tiles alone; the whole image would take the host minutes,
   c2 is compared in full above)."""
-  n, w, h = 3_000_000, 1920, 1080
   g, cams = synthetic.scene_b(n, w, h, sh_degree=3, seed=1, num_cameras=8)
   cam = cams[0]
   camd = cam.to("cuda")
   tiles_x, tiles_y = (w + 15) // 16, (h + 15) // 16
   gen = torch.Generator().manual_seed(0)
-  tiles = torch.randperm(tiles_x * tiles_y, generator=gen)[:384]
+  tiles = torch.randperm(tiles_x * tiles_y, generator=gen)[:ntiles]
   mask = torch.zeros(h, w, dtype=torch.bool)
   for t in tiles.tolist():
     ty, tx = t // tiles_x, t % tiles_x
@@ -271,15 +275,14 @@ def test_config3_full_size_sampled_tiles_match_oracle():
   g2d, depth, sscale = oracle.project(ol[0], ol[1], ol[2], ol[3], idx, T, proj, CFG)
   R = T[:3, :3]
   feats = oracle.evaluate_sh_at(ol[4], ol[0], idx, -(R.t() @ T[:3, 3]))
-  label = "c3 full size 3M 1080p SH3"
   assert observe(label, "depth", r.points.depths, depth.detach(), TOL)[0] < TOL
   assert observe(label, "screen_scale", r.points.screen_scale, sscale.detach(), TOL)[0] < TOL
   # the sort keys: HIP's fp32 depths ARE the oracle's depths rounded to fp32 (gsr_math.h: the depth is formed in double
   # and rounded once), so a stable fp32 argsort of the oracle's depths is the order the HIP frame was composited in
   depth32 = depth.detach().float().reshape(-1)
   differ = int((r.points.depths.detach().cpu().reshape(-1) != depth32).sum())
-  print(f"c3: HIP depth != fp32(oracle depth) at {differ} of {depth32.numel()} splats")
-  assert differ <= 3
+  print(f"{label}: HIP depth != fp32(oracle depth) at {differ} of {depth32.numel()} splats")
+  assert differ <= 10
   g2d_d, feats_d = g2d.detach().requires_grad_(True), feats.detach().requires_grad_(True)
   order_depth = depth32.to(dt)                     # order by the fp32 keys (ties by index), values stay the oracle's own
   lists = oracle._tile_lists(g2d_d, order_depth, (w, h), CFG)
@@ -287,6 +290,8 @@ def test_config3_full_size_sampled_tiles_match_oracle():
   fT_o = torch.ones(h, w, dtype=dt)
   M = idx.shape[0]
   prune, split = torch.zeros(M, dtype=dt), torch.zeros(M, dtype=dt)
+  pmargin, smargin = torch.full((h, w), float("inf"), dtype=dt), torch.full((M,), float("inf"), dtype=dt)
+  omargin = smargin.clone()
   for c0 in range(0, tiles.numel(), 96):
     chunk = tiles[c0:c0 + 96]
     out = oracle.rasterize(g2d_d, order_depth, feats_d, (w, h), CFG, tiles=chunk, lists=lists)
@@ -300,34 +305,48 @@ def test_config3_full_size_sampled_tiles_match_oracle():
     (((img.clamp(0, 1) - 0.5) ** 2) * cm[..., None]).sum().div(norm).mul(100.0).backward()
     with torch.no_grad():
       heur = oracle.rasterize(g2d_d.detach(), order_depth, feats_d.detach(), (w, h), CFG, tiles=chunk, lists=lists,
-                              dL_dimage=img.grad)
+                              dL_dimage=img.grad, want_margins=True)
+      pmargin, smargin = torch.minimum(pmargin, heur.pixel_margin), torch.minimum(smargin, heur.splat_margin)
+      omargin = torch.minimum(omargin, heur.splat_own_margin)
       img_o += out.image.detach() * cm[..., None]
       fT_o = torch.where(cm, out.final_T, fT_o)
       prune += heur.prune_cost
       split += heur.split_score
   torch.autograd.backward([g2d, feats], [g2d_d.grad, feats_d.grad])
   img, fT = r.image.detach().cpu(), r.final_transmittance.cpu()
-  worst_i, frac_i = observe(label, "image (384 tiles)", img[mask], img_o[mask], TOL)
-  worst_t, frac_t = observe(label, "final_T (384 tiles)", fT[mask], fT_o[mask], TOL)
-  assert frac_i <= 1e-4 and frac_t <= 1e-4 and worst_i < 1e-2 and worst_t < 1e-2, (worst_i, frac_i, worst_t, frac_t)
+  worst_i, frac_i = observe(label, f"image ({ntiles} tiles)", img[mask], img_o[mask], TOL)
+  worst_t, frac_t = observe(label, f"final_T ({ntiles} tiles)", fT[mask], fT_o[mask], TOL)
+  # (shares observed: c3 3.7e-5 of the image entries, c5 1.4e-4; each of those entries must be an explained flip, below)
+  assert frac_i <= 4e-4 and frac_t <= 4e-4 and worst_i < 1e-2 and worst_t < 1e-2, (worst_i, frac_i, worst_t, frac_t)
   orc = dict(d_position=ol[0].grad, d_log_scaling=ol[1].grad, d_rotation=ol[2].grad, d_alpha_logit=ol[3].grad,
              d_feature=ol[4].grad, prune_cost=prune, split_score=split)
   for k in ("d_position", "d_log_scaling", "d_rotation", "d_alpha_logit", "d_feature", "prune_cost", "split_score"):
-    worst, frac = observe(label + " (loss on 384 tiles)", k, hip[k], orc[k], TOL)
+    worst, frac = observe(label + f" (loss on {ntiles} tiles)", k, hip[k], orc[k], TOL)
     assert frac <= 2e-4 and worst < 1e-2, (k, worst, frac)
     assert orc[k].abs().max() > 0
+  # every entry above tol: an explained flip (a pixel / a splat within FLIP_ULPS of a decision boundary of the oracle's walk)
+  m3 = mask[..., None]
+  compare_explained(label + " (explained flips)",
+                    dict(hip, idx=r.points.idx, image=img * m3, final_T=torch.where(mask, fT, torch.ones_like(fT))),
+                    dict(orc, idx=idx, image=img_o * m3, final_T=torch.where(mask, fT_o, torch.ones_like(fT_o)),
+                         pixel_margin=pmargin, splat_margin=smargin, splat_own_margin=omargin, g2d=g2d.detach()), TOL,
+                    keys=("image", "final_T", "d_position", "d_log_scaling", "d_rotation", "d_alpha_logit", "d_feature",
+                          "prune_cost", "split_score"))
 
 
-@pytest.mark.parametrize("n,w,h,deg", [(3_000_000, 1920, 1080, 3), (10_000_000, 3840, 2160, 3)])
-def test_full_size_properties_large_configs(n, w, h, deg):
-  """BASELINE.json configs[2] / configs[4] sizes (3M at 1080p; 10M at 4K with the frustum cull active), one camera.
+@pytest.mark.parametrize("n,w,h,deg,radius", [(3_000_000, 1920, 1080, 3, 3.0), (10_000_000, 3840, 2160, 3, 3.0),
+                                              (10_000_000, 3840, 2160, 3, 1.2)])
+def test_full_size_properties_large_configs(n, w, h, deg, radius):
+  """BASELINE.json configs[2] / configs[4] sizes (3M at 1080p; 10M at 4K with the frustum cull active), one camera; and
+  c5's CULLED variant (orbit of radius 1.2 around the unit ball, so that the frustum cull removes
+  roughly half of the 10M points -- K1 at scale, and every size-dependent buffer sized from M < N).
   Properties that need no oracle:
      (1) unit features: image + final_T == 1 at every pixel;
      (2) d(sum image)/d feature == visibility;
      (3) the backward pass is linear in dL/dimage, and scaling by a power of two is exact in fp32: every gradient and
          heuristic of the run with 4 x dL/dimage is bit-for-bit 4 x the first run's;
      (4) indexes ascending, inside [0, N), depths within [near, far]."""
-  g, cams = synthetic.scene_b(n, w, h, sh_degree=deg, seed=1, num_cameras=8)
+  g, cams = synthetic.scene_b(n, w, h, sh_degree=deg, seed=1, num_cameras=8, radius=radius)
   cam = cams[0].to("cuda")
   cfg = sta.RasterConfig(compute_visibility=True, compute_point_heuristic=True)
   leaves = [t.cuda().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)]
@@ -336,6 +355,14 @@ def test_full_size_properties_large_configs(n, w, h, deg):
   with torch.no_grad():
     g2d, depth, idx = sta.project_to_image(scene, cam, cfg)
     m = idx.numel()
+    print(f"properties at N = {n}, {w}x{h}, orbit radius {radius}: M = {m} visible ({100.0 * m / n:.1f} %)")
+    if radius < 2.0:
+      assert 0.3 * n < m < 0.75 * n, m                    # the cull really removes a large part of the scene
+      # the visible set is exactly the points the margin-expanded frustum test keeps (fp64 restatement of K1's test)
+      want = oracle.frustum_cull(g.position.double(), cams[0].T_camera_world.double(), cams[0].projection.double(),
+                                 (w, h), cams[0].near_plane, cams[0].far_plane, cfg.margin_tiles * cfg.tile_size)
+      diff = len(set(idx.cpu().tolist()) ^ set(want.tolist()))
+      assert diff <= 3, diff                              # (a point exactly on a frustum plane may round either way)
     assert 0 < m <= n and bool((idx[1:] > idx[:-1]).all()) and int(idx[-1]) < n
     assert float(depth.min()) >= cam.near_plane and float(depth.max()) <= cam.far_plane
   ones = torch.ones(m, 1, device="cuda", requires_grad=True)

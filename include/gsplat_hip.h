@@ -84,7 +84,7 @@ typedef struct GsrSegmentsC {
 /* sizeof of the ABI's structs as the library was compiled: 0 GsrRasterParamsC, 1 GsrSegmentsC, 2 GsrFrameC,
  * 3 GsrFramePlanC, 4 GsrFrameResultC, 5 GsrFrameBackwardC (-1 otherwise) -- for a binding to check its own layout. */
 int64_t gsr_struct_bytes(int32_t which);
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 27) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 28) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -533,6 +533,28 @@ int gsr_dp_pack(const int64_t* idx, const float* dL_dcolors, const float* split_
 int gsr_dp_replay(const float* blocks, int64_t stride, const int32_t* slots, int32_t num_cameras, int64_t N,
                   float split_alpha, float prune_alpha, float* state_split_score, float* state_prune_cost,
                   float* state_max_scale_px, const float* visibility_sum, const float* views_sum,
+                  float* state_visibility, int16_t* state_points_in_view, void* stream);
+
+/* Sharded form of the exchange (default since round 4).  L = ceil(N / num_ranks); rank r owns the points [r L, (r+1) L).
+ * gsr_dp_pack_sharded fills, for ONE camera of this rank (slot of slots_per_rank): factors_out (3N + 3 floats: the
+ * camera's all-gather block, colour-gradient rows + camera position -- the input of gsr_sh_backward_multi); its two
+ * controller scores in the all-to-all SEND layout scores_out[dest rank][slot][field][L] (field 0 split_score, 1
+ * prune_cost; NaN where unseen); the running maximum of the larger screen-space sigma over this rank's cameras in
+ * scale_max[N] (finished by a MAX all-reduce); and the two sums as gsr_dp_pack does.
+ * gsr_dp_replay_slice applies the two exp_lerp EMAs (point_state.py:49-50) of ALL cameras of the batch in camera order
+ * (camera c arrived from rank c % num_ranks in slot c / num_ranks: recv[src rank][slot][field][L]) to this rank's slice
+ * of the state and leaves the slice's new values in slice_out[field][L], the all-gather send buffer.
+ * gsr_dp_finish writes the gathered slices (gathered[rank][field][L]) back into the N-sized state and folds the reduced
+ * maximum and sums (any of the two groups may be NULL). */
+int gsr_dp_pack_sharded(const int64_t* idx, const float* dL_dcolors, const float* split_score, const float* prune_cost,
+                        const float* screen_scale, int32_t scale_cols, const float* camera_pos, int64_t M, int64_t N,
+                        int32_t num_ranks, int32_t slots_per_rank, int32_t slot, float* factors_out, float* scores_out,
+                        float* scale_max, const float* visibility, float* visibility_sum, float* views_sum, void* stream);
+int gsr_dp_replay_slice(const float* recv, int32_t num_ranks, int32_t slots_per_rank, int64_t N, int32_t rank,
+                        int32_t num_cameras, float split_alpha, float prune_alpha, const float* state_split_score,
+                        const float* state_prune_cost, float* slice_out, void* stream);
+int gsr_dp_finish(const float* gathered, int32_t num_ranks, int64_t N, float* state_split_score, float* state_prune_cost,
+                  const float* scale_max, float* state_max_scale_px, const float* visibility_sum, const float* views_sum,
                   float* state_visibility, int16_t* state_points_in_view, void* stream);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -149,6 +149,9 @@ PROTOTYPES = {
     "gsr_point_basis": (C.c_int, [_p, _p, _p, _i64, _f, _p, _p]),
     "gsr_dp_pack": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "gsr_dp_replay": (C.c_int, [_p, _i64, _p, _i32, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "gsr_dp_pack_sharded": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "gsr_dp_replay_slice": (C.c_int, [_p, _i32, _i32, _i64, _i32, _i32, _f, _f, _p, _p, _p, _p]),
+    "gsr_dp_finish": (C.c_int, [_p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_point_state_add": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "gsr_frame_plan": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC)]),
     "gsr_struct_bytes": (_i64, [_i32]),
@@ -201,6 +204,12 @@ def load() -> C.CDLL:
       fn.argtypes = argtypes
     if lib.gsr_abi_version() != ABI_VERSION:
       raise GsplatHipError(f"ABI mismatch: library {lib.gsr_abi_version()} != binding {ABI_VERSION}; rebuild")
+    # the ctypes mirrors of the ABI's structs must have the layout the library was compiled with (gsr_struct_bytes)
+    for which, mirror in enumerate((GsrRasterParamsC, GsrSegmentsC, GsrFrameC, GsrFramePlanC, GsrFrameResultC,
+                                    GsrFrameBackwardC)):
+      if lib.gsr_struct_bytes(which) != C.sizeof(mirror):
+        raise GsplatHipError(f"struct layout mismatch: {mirror.__name__} is {C.sizeof(mirror)} bytes in the binding, "
+                             f"{lib.gsr_struct_bytes(which)} in the library; rebuild")
     _lib = lib
   return _lib
 

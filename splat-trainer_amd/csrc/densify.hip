@@ -303,6 +303,93 @@ __global__ __launch_bounds__(DN_THREADS) void dp_replay_kernel(const float* __re
   st_scale[i] = mx;
 }
 
+// ---- sharded exchange (round 4): the colour-gradient factors still reach every rank (every rank rebuilds the SH gradient
+// of ALL points), but the two order-dependent controller scores only have to be REPLAYED in camera order, not on every rank:
+// rank r replays the points [r L, (r + 1) L) for all cameras and the 2-float state of its slice is all-gathered afterwards.
+// dp_pack_sharded_kernel writes this camera's scores straight into the all-to-all send layout [dest rank][slot][field][L].
+__global__ __launch_bounds__(DN_THREADS) void dp_fill_sharded_kernel(float* __restrict__ factors, float* __restrict__ scores,
+                                                                     int64_t N, int64_t L, int32_t cpr, int32_t slot) {
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (i < 3 * N) factors[i] = 0.f;
+  if (i < N) {
+    const int64_t r = i / L, o = i - r * L;
+    float* cell = scores + ((r * cpr + slot) * 2) * L + o;
+    cell[0] = __uint_as_float(0x7fc00000u);
+    cell[L] = __uint_as_float(0x7fc00000u);
+  }
+}
+
+__global__ __launch_bounds__(DN_THREADS) void dp_pack_sharded_kernel(
+    const int64_t* __restrict__ idx, const float* __restrict__ dcol, const float* __restrict__ split,
+    const float* __restrict__ prune, const float* __restrict__ scale, int scale_cols, const float* __restrict__ campos,
+    int64_t M, int64_t N, int64_t L, int32_t cpr, int32_t slot, float* __restrict__ factors, float* __restrict__ scores,
+    float* __restrict__ scale_max, const float* __restrict__ vis, float* __restrict__ vis_sum,
+    float* __restrict__ views_sum) {
+  const int64_t m = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (m < 3) factors[3 * N + m] = campos[m];
+  if (m >= M) return;
+  const int64_t i = idx ? idx[m] : m;
+  if (vis) {                                        // this rank's share of the two per-point SUMS (rows unique per camera)
+    const float v = vis[m];
+    vis_sum[i] += v;
+    if (v > 0.f) views_sum[i] += 1.f;
+  }
+  factors[3 * i] = dcol[3 * m];
+  factors[3 * i + 1] = dcol[3 * m + 1];
+  factors[3 * i + 2] = dcol[3 * m + 2];
+  const int64_t r = i / L, o = i - r * L;
+  float* cell = scores + ((r * cpr + slot) * 2) * L + o;
+  cell[0] = split[m];
+  cell[L] = prune[m];
+  float sc = scale[m * scale_cols];
+  if (scale_cols == 2) sc = fmaxf(sc, scale[m * 2 + 1]);
+  scale_max[i] = fmaxf(scale_max[i], sc);           // over this rank's cameras; a MAX all-reduce finishes it
+}
+
+// recv[q][s][f][o]: field f of camera (q + s G) at point lo + o, NaN where that camera did not see the point.
+__global__ __launch_bounds__(DN_THREADS) void dp_replay_slice_kernel(const float* __restrict__ recv, int32_t G, int32_t cpr,
+                                                                     int64_t L, int32_t num_cameras, int64_t lo,
+                                                                     int64_t count, float split_alpha, float prune_alpha,
+                                                                     const float* __restrict__ st_split,
+                                                                     const float* __restrict__ st_prune,
+                                                                     float* __restrict__ slice_out) {
+  const int64_t o = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (o >= count) return;
+  float s = st_split[lo + o], p = st_prune[lo + o];
+  for (int c = 0; c < num_cameras; ++c) {
+    const int64_t q = c % G, sl = c / G;
+    const float* cell = recv + ((q * cpr + sl) * 2) * L + o;
+    const float v = cell[0];
+    if (v == v) {
+      s = exp_lerp(split_alpha, s, v);
+      p = exp_lerp(prune_alpha, p, cell[L]);
+    }
+  }
+  slice_out[o] = s;
+  slice_out[L + o] = p;
+}
+
+// gathered[r][f][o] -> state; the all-reduced maximum and sums folded in.
+__global__ __launch_bounds__(DN_THREADS) void dp_finish_kernel(const float* __restrict__ gathered, int64_t L, int64_t N,
+                                                               float* __restrict__ st_split, float* __restrict__ st_prune,
+                                                               const float* __restrict__ scale_max,
+                                                               float* __restrict__ st_scale,
+                                                               const float* __restrict__ vis_sum,
+                                                               const float* __restrict__ views_sum,
+                                                               float* __restrict__ st_vis, int16_t* __restrict__ st_views) {
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (i >= N) return;
+  const int64_t r = i / L, o = i - r * L;
+  const float* cell = gathered + (r * 2) * L + o;
+  st_split[i] = cell[0];
+  st_prune[i] = cell[L];
+  if (scale_max) st_scale[i] = fmaxf(st_scale[i], scale_max[i]);
+  if (vis_sum) {
+    st_vis[i] += vis_sum[i];
+    st_views[i] = (int16_t)(st_views[i] + (int16_t)views_sum[i]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -356,6 +443,65 @@ int gsr_dp_replay(const float* blocks, int64_t stride, const int32_t* slots, int
                                                                      prune_alpha, state_split_score, state_prune_cost,
                                                                      state_max_scale_px, visibility_sum, views_sum,
                                                                      state_visibility, state_points_in_view);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_dp_pack_sharded(const int64_t* idx, const float* dL_dcolors, const float* split_score, const float* prune_cost,
+                        const float* screen_scale, int32_t scale_cols, const float* camera_pos, int64_t M, int64_t N,
+                        int32_t num_ranks, int32_t slots_per_rank, int32_t slot, float* factors_out, float* scores_out,
+                        float* scale_max, const float* visibility, float* visibility_sum, float* views_sum, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || N < 3 || M > N || (scale_cols != 1 && scale_cols != 2) || num_ranks < 1 || slots_per_rank < 1 || slot < 0 ||
+      slot >= slots_per_rank || !factors_out || !scores_out || !scale_max || !camera_pos)
+    return GSR_ERR_INVALID_ARGUMENT;
+  if (visibility && (!visibility_sum || !views_sum)) return GSR_ERR_INVALID_ARGUMENT;
+  if (M > 0 && (!dL_dcolors || !split_score || !prune_cost || !screen_scale)) return GSR_ERR_INVALID_ARGUMENT;
+  const int64_t L = (N + num_ranks - 1) / num_ranks;
+  if (M < N) {                                      // rows the camera did not see: zero gradient, NaN scores
+    dp_fill_sharded_kernel<<<dn_grid(3 * N, DN_THREADS), DN_THREADS, 0, stream>>>(factors_out, scores_out, N, L,
+                                                                                slots_per_rank, slot);
+    GSR_CHECK_LAUNCH();
+  }
+  dp_pack_sharded_kernel<<<dn_grid(M > 3 ? M : 3, DN_THREADS), DN_THREADS, 0, stream>>>(
+      idx, dL_dcolors, split_score, prune_cost, screen_scale, scale_cols, camera_pos, M, N, L, slots_per_rank, slot,
+      factors_out, scores_out, scale_max, visibility, visibility_sum, views_sum);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_dp_replay_slice(const float* recv, int32_t num_ranks, int32_t slots_per_rank, int64_t N, int32_t rank,
+                        int32_t num_cameras, float split_alpha, float prune_alpha, const float* state_split_score,
+                        const float* state_prune_cost, float* slice_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || num_ranks < 1 || slots_per_rank < 1 || rank < 0 || rank >= num_ranks || num_cameras < 0 ||
+      num_cameras > num_ranks * slots_per_rank)
+    return GSR_ERR_INVALID_ARGUMENT;
+  const int64_t L = (N + num_ranks - 1) / num_ranks;
+  const int64_t lo = (int64_t)rank * L, count = lo < N ? (N - lo < L ? N - lo : L) : 0;
+  if (count == 0) return GSR_OK;
+  if (!recv || !state_split_score || !state_prune_cost || !slice_out) return GSR_ERR_INVALID_ARGUMENT;
+  dp_replay_slice_kernel<<<dn_grid(count, DN_THREADS), DN_THREADS, 0, stream>>>(recv, num_ranks, slots_per_rank, L,
+                                                                               num_cameras, lo, count, split_alpha,
+                                                                               prune_alpha, state_split_score,
+                                                                               state_prune_cost, slice_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_dp_finish(const float* gathered, int32_t num_ranks, int64_t N, float* state_split_score, float* state_prune_cost,
+                  const float* scale_max, float* state_max_scale_px, const float* visibility_sum, const float* views_sum,
+                  float* state_visibility, int16_t* state_points_in_view, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (N < 0 || num_ranks < 1) return GSR_ERR_INVALID_ARGUMENT;
+  if (N == 0) return GSR_OK;
+  if (!gathered || !state_split_score || !state_prune_cost) return GSR_ERR_INVALID_ARGUMENT;
+  if (scale_max && !state_max_scale_px) return GSR_ERR_INVALID_ARGUMENT;
+  if (visibility_sum && (!views_sum || !state_visibility || !state_points_in_view)) return GSR_ERR_INVALID_ARGUMENT;
+  const int64_t L = (N + num_ranks - 1) / num_ranks;
+  dp_finish_kernel<<<dn_grid(N, DN_THREADS), DN_THREADS, 0, stream>>>(gathered, L, N, state_split_score, state_prune_cost,
+                                                                     scale_max, state_max_scale_px, visibility_sum,
+                                                                     views_sum, state_visibility, state_points_in_view);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

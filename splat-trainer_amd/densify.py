@@ -214,3 +214,94 @@ def dp_replay(state, blocks: torch.Tensor, slots: torch.Tensor, num_points: int,
                                _p(state.visibility) if sums is not None else None,
                                _p(state.points_in_view) if sums is not None else None, _stream()), "gsr_dp_replay")
   return state
+
+
+# ---------------------------------------------------------------------------------- sharded exchange (round 4)
+def dp_slice_len(num_points: int, num_ranks: int) -> int:
+  """L = ceil(N / G): rank r owns the points [r L, (r + 1) L) of the order-dependent controller state."""
+  return (int(num_points) + int(num_ranks) - 1) // int(num_ranks)
+
+
+def dp_pack_sharded(factors: torch.Tensor, scores: torch.Tensor, scale_max: torch.Tensor, num_points: int, slot: int,
+                    idx: torch.Tensor, d_colour: torch.Tensor, split_score: torch.Tensor, prune_cost: torch.Tensor,
+                    screen_scale: torch.Tensor, camera_pos: torch.Tensor, visibility: Optional[torch.Tensor] = None,
+                    sums: Optional[torch.Tensor] = None):
+  """One camera of this rank into the sharded exchange's send buffers (layouts in gsplat_hip.h: gsr_dp_pack_sharded):
+  ``factors`` (3 N + 3,) the camera's all-gather block (colour gradient rows, 0 where unseen, + camera position);
+  ``scores`` (G, slots_per_rank, 2, L) the all-to-all send buffer, this camera's split_score / prune_cost (NaN where
+  unseen) in slot ``slot``; ``scale_max`` (N,) running maximum of the larger screen-space sigma over this rank's cameras;
+  ``visibility`` + ``sums`` as in dp_pack.  CPU tensors (the gloo tests): the same with torch ops."""
+  N, M = int(num_points), int(idx.shape[0])
+  G, cpr, _, L = scores.shape
+  if factors.numel() != 3 * N + 3 or L != dp_slice_len(N, G) or scale_max.numel() != N:
+    raise ValueError("dp_pack_sharded: buffer shapes do not match (N, ranks)")
+  f32 = lambda t: t.detach().to(torch.float32).contiguous()
+  scale = f32(screen_scale)
+  if not factors.is_cuda:
+    factors[:3 * N] = 0
+    factors[:3 * N].view(N, 3).index_copy_(0, idx, f32(d_colour))
+    factors[3 * N:] = f32(camera_pos)
+    dense = torch.full((2, G * L), float("nan"))
+    dense[0, idx], dense[1, idx] = f32(split_score), f32(prune_cost)
+    scores[:, slot] = dense.view(2, G, L).permute(1, 0, 2)
+    sc = scale.max(1).values if scale.dim() == 2 else scale
+    scale_max[idx] = torch.maximum(scale_max[idx], sc)
+    if visibility is not None:
+      sums[:N].index_add_(0, idx, f32(visibility))
+      sums[N:].index_add_(0, idx, (visibility > 0).to(torch.float32))
+    return
+  cols = 2 if scale.dim() == 2 else 1
+  _lib.check(_lib.load().gsr_dp_pack_sharded(
+      _p(idx.contiguous()) if M < N else None, _p(f32(d_colour)), _p(f32(split_score)), _p(f32(prune_cost)), _p(scale), cols,
+      _p(f32(camera_pos)), M, N, int(G), int(cpr), int(slot), _p(factors), _p(scores), _p(scale_max),
+      _p(f32(visibility)) if visibility is not None else None, _p(sums[:N]) if visibility is not None else None,
+      _p(sums[N:]) if visibility is not None else None, _stream()), "gsr_dp_pack_sharded")
+
+
+def dp_replay_slice(state, recv: torch.Tensor, rank: int, num_cameras: int, num_points: int, slice_out: torch.Tensor,
+                    split_alpha: float = 0.01, prune_alpha: float = 0.1):
+  """The two order-dependent EMAs of PointState.add_rendering (point_state.py:49-50) of ALL cameras of the batch, in
+  camera order, on THIS rank's slice of the points: ``recv`` (G, slots_per_rank, 2, L) is what the all-to-all delivered
+  (camera c came from rank c % G, slot c // G); the slice's new (split_score, prune_cost) go to ``slice_out`` (2, L),
+  the all-gather send buffer.  ``state`` itself is not modified (dp_finish writes the gathered slices back)."""
+  G, cpr, _, L = recv.shape
+  N = int(num_points)
+  lo = rank * L
+  count = max(0, min(L, N - lo))
+  if not recv.is_cuda:
+    from .controller_math import exp_lerp
+    s, p = state.split_score[lo:lo + count].clone(), state.prune_cost[lo:lo + count].clone()
+    for c in range(num_cameras):
+      cell = recv[c % G, c // G]
+      seen = ~torch.isnan(cell[0, :count])
+      s[seen] = exp_lerp(split_alpha, s[seen], cell[0, :count][seen])
+      p[seen] = exp_lerp(prune_alpha, p[seen], cell[1, :count][seen])
+    slice_out[0, :count], slice_out[1, :count] = s, p
+    return
+  _lib.check(_lib.load().gsr_dp_replay_slice(_p(recv), int(G), int(cpr), N, int(rank), int(num_cameras), float(split_alpha),
+                                             float(prune_alpha), _p(state.split_score), _p(state.prune_cost),
+                                             _p(slice_out), _stream()), "gsr_dp_replay_slice")
+
+
+def dp_finish(state, gathered: torch.Tensor, num_points: int, scale_max: Optional[torch.Tensor] = None,
+              sums: Optional[torch.Tensor] = None):
+  """Writes the all-gathered state slices (G, 2, L) back into ``state.split_score`` / ``state.prune_cost`` and folds the
+  MAX-all-reduced screen scale and the SUM-all-reduced visibility / in-view count into the state."""
+  G, _, L = gathered.shape
+  N = int(num_points)
+  if not gathered.is_cuda:
+    flat = gathered.permute(1, 0, 2).reshape(2, G * L)
+    state.split_score.copy_(flat[0, :N])
+    state.prune_cost.copy_(flat[1, :N])
+    if scale_max is not None:
+      torch.maximum(state.max_scale_px, scale_max, out=state.max_scale_px)
+    if sums is not None:
+      state.visibility += sums[:N]
+      state.points_in_view += sums[N:].to(state.points_in_view.dtype)
+    return state
+  _lib.check(_lib.load().gsr_dp_finish(_p(gathered), int(G), N, _p(state.split_score), _p(state.prune_cost),
+                                       _p(scale_max), _p(state.max_scale_px) if scale_max is not None else None,
+                                       _p(sums[:N]) if sums is not None else None, _p(sums[N:]) if sums is not None else None,
+                                       _p(state.visibility) if sums is not None else None,
+                                       _p(state.points_in_view) if sums is not None else None, _stream()), "gsr_dp_finish")
+  return state

@@ -376,7 +376,8 @@ class CameraShardedStep:
 
   def __init__(self, params: Sequence[torch.Tensor], world_size: int, rank: int, group=None,
                mode: str = DEFAULT_COLLECTIVE, with_stats: bool = True, packed: bool = False,
-               exchange_when_single: bool = False, fused_grad_out: bool = True, position_term_local: bool = True):
+               exchange_when_single: bool = False, fused_grad_out: bool = True, position_term_local: bool = True,
+               sharded_replay: bool = True):
     """``packed``: exchange rows padded to the batch's largest visible count instead of the dense per-point block
     (needs a count exchange + host sync per batch).  ``exchange_when_single``: run the exchange even with one rank
     (tests: packing, the collectives on a one-rank group, rebuild and replay on a single GPU).
@@ -384,6 +385,10 @@ class CameraShardedStep:
     ``project_to_image``, whose first backward pass of a batch initialises the gradient buffers itself (every row
     written, zeros where its camera saw nothing): no zero-fill per batch.  False: the buffers are zero-filled per batch
     and the callback may accumulate into ``param.grad`` any way it likes.
+    ``sharded_replay`` (default): the order-dependent controller scores are exchanged by POINTS, not replayed on every
+    rank -- all-to-all of each rank's N / G slice of every camera's scores, in-order replay on the slice, all-gather of the
+    2-float state -- and the screen-scale maximum travels as a MAX all-reduce (``_exchange_sharded``); False: the round-3
+    form, one dense 6 N + 3 block per camera all-gathered and replayed on every rank (``_exchange_dense``).
     ``position_term_local`` (default; factor exchange only): every rank adds the position term of its own cameras'
     colour gradient before the all-reduce -- ``render_gaussians(use_sh=True, sh_collector=...)`` does, from the Jacobian
     its forward pass saves -- and the multi-camera rebuild neither recomputes it for all cameras on every rank nor
@@ -395,6 +400,7 @@ class CameraShardedStep:
     self.params = list(params)
     self.world, self.rank, self.group, self.mode, self.with_stats = max(world_size, 1), rank, group, mode, with_stats
     self.packed = packed
+    self.sharded = bool(sharded_replay)
     self.exchange = self.world > 1 or exchange_when_single
     self.factor = mode == "sh_factor" and self.exchange
     self._slots = {}
@@ -476,7 +482,7 @@ class CameraShardedStep:
     if not self.exchange:
       return [] if light else local
     if dense:
-      self._exchange_dense(len(cameras), local, point_state)
+      (self._exchange_sharded if self.sharded else self._exchange_dense)(len(cameras), local, point_state)
       return []
     cpr = (len(cameras) + self.world - 1) // self.world
     counts = exchange_counts([(d["camera"], d["idx"].shape[0]) for d in local] if (self.with_stats or light) else
@@ -571,3 +577,76 @@ class CameraShardedStep:
                                                  _lib.current_stream_ptr()), "gsr_sh_backward_multi")
     self.collector.clear()
     dp_replay(point_state, blocks, self.camera_slots(num_cameras, position.device), N, sums=self.bucket.extra)
+
+  # ---------------------------------------------------------------------------------------- sharded exchange
+  def _exchange_sharded(self, num_cameras: int, local: List[dict], point_state):
+    """The default exchange since round 4.  Per batch, G ranks, ``cpr`` camera slots per rank, L = ceil(N / G):
+
+      1. all_reduce SUM (async)   geometry gradients + visible accumulator + in-view count: 13 floats per point
+      2. all_reduce MAX (async)   larger screen-space sigma (point_state.py:37): 1 float per point
+      3. all_gather               one (3 N + 3)-float block per camera: the colour-gradient factors every rank rebuilds the
+                                  summed SH coefficient gradient from (48 of the 59 gradient floats never cross xGMI)
+      4. all_to_all               each camera's split_score / prune_cost cut into G slices: rank r receives, of every
+                                  camera of the batch, the L points it owns (2 L floats per camera)
+      5. (local) the two exp_lerp EMAs of all cameras IN CAMERA ORDER on the L owned points (point_state.py:49-50)
+      6. all_gather               the slice's new state, 2 L floats per rank
+
+    No host sync.  Against the dense form (one 6 N + 3 block per camera to every rank) a rank receives 3 N + 2 N / G
+    floats per camera instead of 6 N, and the replay costs N / G instead of N point-visits per camera."""
+    import ctypes as C
+    from . import _lib
+    from .densify import dp_finish, dp_pack_sharded, dp_replay_slice, dp_slice_len
+    position, feature = self.params[0], self.params[4]
+    N, K, dev = position.shape[0], feature.shape[2], position.device
+    G = self.world
+    cpr = (num_cameras + G - 1) // G
+    L = dp_slice_len(N, G)
+    live = dist.is_available() and dist.is_initialized()
+    factors = torch.empty(cpr, 3 * N + 3, dtype=torch.float32, device=dev)
+    scores = torch.empty(G, cpr, 2, L, dtype=torch.float32, device=dev)
+    self.scale_max.zero_()
+    empty_i = torch.empty(0, dtype=torch.int64, device=dev)
+    empty_f = torch.empty(0, dtype=torch.float32, device=dev)
+    items = self.collector.items
+    for s in range(cpr):
+      if s < len(local):
+        d, (idx, d_colour, cam) = local[s], items[s]
+        dp_pack_sharded(factors[s], scores, self.scale_max, N, s, idx, d_colour, d["split_score"], d["prune_cost"],
+                        d["screen_scale"], cam, visibility=d.get("visibility"), sums=self.bucket.extra)
+      else:                                  # an unused slot carries an empty camera: zero gradient, NaN scores
+        dp_pack_sharded(factors[s], scores, self.scale_max, N, s, empty_i, empty_f.view(0, 3), empty_f, empty_f,
+                        empty_f.view(0, 2), torch.zeros(3, dtype=torch.float32, device=dev))
+    # (the packs above also added this rank's cameras to the two sum columns the gradient all-reduce carries)
+    pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True, even_single=True) if live else None
+    pending_max = dist.all_reduce(self.scale_max, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if live else None
+    if live:
+      blocks = torch.empty(G * cpr, 3 * N + 3, dtype=torch.float32, device=dev)
+      dist.all_gather_into_tensor(blocks, factors, group=self.group)
+      recv = torch.empty_like(scores)
+      dist.all_to_all_single(recv, scores, group=self.group)
+    else:
+      blocks, recv = factors, scores
+    mine = torch.empty(2, L, dtype=torch.float32, device=dev)
+    dp_replay_slice(point_state, recv, self.rank, num_cameras, N, mine)
+    if live:
+      gathered = torch.empty(G, 2, L, dtype=torch.float32, device=dev)
+      dist.all_gather_into_tensor(gathered.view(G * 2, L), mine, group=self.group)
+    else:
+      gathered = mine.view(1, 2, L)
+    if pending is not None:
+      pending.wait()                                   # d_pos below adds to the all-reduced position gradient
+    if pending_max is not None:
+      pending_max.wait()
+    width = blocks.shape[1]
+    base = blocks.data_ptr()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    position_done = self.collector.position_term_local or K == 1
+    if blocks.is_cuda:
+      _lib.check(_lib.load().gsr_sh_backward_multi(C.c_void_p(base), width, C.c_void_p(base + 4 * 3 * N), width,
+                                                   blocks.shape[0], ptr(feature.detach()), ptr(position.detach()), N, K,
+                                                   ptr(self.feature_grad),
+                                                   None if position_done else ptr(self.bucket.views[0]), 0,
+                                                   _lib.current_stream_ptr()), "gsr_sh_backward_multi")
+    self.collector.clear()
+    dp_finish(point_state, gathered, N, scale_max=self.scale_max, sums=self.bucket.extra)
+    self.last_blocks = blocks                          # (tests look at what was gathered)

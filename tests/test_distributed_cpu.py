@@ -198,9 +198,32 @@ def _stats_worker(rank, world, port, out_path, num_cameras):
   replayed = PointState.new_zeros(n, "cpu")
   for _ in range(2):
     dp_replay(replayed, blocks, dd.camera_slots(num_cameras, "cpu"), n)
+  # the DEFAULT exchange since round 4 (sharded replay), end to end through CameraShardedStep.run on gloo: gradient
+  # all-reduce, MAX all-reduce of the screen scale, all-gather of the colour-factor blocks, all-to-all of the score slices,
+  # in-order replay on the owned slice, all-gather of the slice state (the SH rebuild kernel itself is HIP-only)
+  ds = CameraShardedStep(params, world, rank)
+
+  def fake_render_dp(j, cam, grad_out, collector):
+    d = _camera_stats(j, n)
+    if grad_out.geometry_uninitialized:                 # the first backward pass of a batch writes every row
+      for t in (grad_out.position, grad_out.log_scaling, grad_out.rotation, grad_out.alpha_logit):
+        t.zero_()
+      grad_out.geometry_uninitialized = False
+    grad_out.position[d["idx"]] += float(j + 1)
+    collector.items.append((d["idx"], d["dcol"], d["cam"]))
+    pts = sta.RenderedPoints(idx=d["idx"], depths=torch.zeros(d["idx"].shape[0], 1), opacity=torch.zeros(d["idx"].shape[0]),
+                             screen_scale=torch.stack([d["screen_scale_max"], 0.5 * d["screen_scale_max"]], dim=1),
+                             visibility=d["visibility"], prune_cost=d["prune_cost"], split_score=d["split_score"])
+    return sta.Rendering(image=None, camera=None, points=pts)
+
+  sharded = PointState.new_zeros(n, "cpu")
+  for _ in range(2):
+    assert ds.run(list(range(num_cameras)), fake_render_dp, point_state=sharded) == []
   torch.save(dict(stats=got, masks=masks, state={f: getattr(state, f) for f in fields}, dense=dense, packed=packed,
                   counts=counts, light={f: getattr(light, f) for f in fields}, visible=dp.visible.clone(),
-                  blocks=blocks, replayed={f: getattr(replayed, f) for f in fields}),
+                  blocks=blocks, replayed={f: getattr(replayed, f) for f in fields},
+                  sharded={f: getattr(sharded, f) for f in fields}, sharded_visible=ds.visible.clone(),
+                  sharded_blocks=ds.last_blocks.clone(), sharded_dpos=ds.grads["position"].clone()),
              f"{out_path}.{rank}")
   dist.barrier()
   dist.destroy_process_group()
@@ -259,6 +282,18 @@ def test_two_rank_point_stats_and_packed_factors(tmp_path, num_cameras):
     m2 = find_split_prune_indexes(PointState(**r["light"]), 0.2, 560, min_views=1, max_scale_px=50.0)
     want = find_split_prune_indexes(twice, 0.2, 560, min_views=1, max_scale_px=50.0)
     assert torch.equal(m2[0], want[0]) and torch.equal(m2[1], want[1])
+  # the sharded exchange (default): everything that enters the masks bit-identical to the sequential loop on both ranks,
+  # the gathered colour-factor blocks equal to the dense factor gather, the all-reduced gradient the sum over all cameras
+  want_dpos = torch.zeros(n, 3)
+  for j, d in enumerate(seq):
+    want_dpos[d["idx"]] += float(j + 1)
+  for r in (r0, r1):
+    for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view"):
+      assert torch.equal(r["sharded"][f], getattr(twice, f)), f
+    assert torch.allclose(r["sharded"]["visibility"], twice.visibility, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(r["sharded_visible"], one.visibility, rtol=1e-6, atol=1e-7)
+    assert torch.equal(r["sharded_blocks"].reshape(-1, n + 1, 3), r["dense"])
+    assert torch.equal(r["sharded_dpos"], want_dpos)
   # dense per-camera blocks: identical on both ranks, the factor part equals the dense factor gather, and the replayed
   # order-dependent state equals the sequential loop's bit for bit
   for r in (r0, r1):

@@ -1,6 +1,7 @@
-"""The default data-parallel exchange (distributed.CameraShardedStep: dense per-camera blocks, two collectives, no host
-sync) on one GPU: packing, RCCL's all-reduce / all-gather on a ONE-rank group, the SH-gradient rebuild over all
-cameras and the in-order replay of the controller statistics, against the sequential per-camera loop."""
+"""The data-parallel exchanges of distributed.CameraShardedStep on one GPU -- the default (sharded replay: SUM and MAX
+all-reduce, all-gather of the colour-factor blocks, all-to-all of the score slices, all-gather of the slice state) and the
+round-3 form (dense per-camera blocks) -- with RCCL's collectives on a ONE-rank group: packing, the SH-gradient rebuild
+over all cameras and the in-order replay of the controller statistics, against the sequential per-camera loop."""
 import os
 
 import pytest
@@ -11,7 +12,8 @@ import splat_trainer_amd as sta
 from helpers import small_scene
 from splat_trainer_amd import synthetic
 from splat_trainer_amd.controller_math import PointState
-from splat_trainer_amd.densify import dp_block_floats, dp_pack, dp_replay
+from splat_trainer_amd.densify import (dp_block_floats, dp_finish, dp_pack, dp_pack_sharded, dp_replay, dp_replay_slice,
+                                       dp_slice_len)
 from splat_trainer_amd.distributed import CameraShardedStep
 
 pytestmark = pytest.mark.gpu
@@ -57,11 +59,12 @@ def _run(g, cams, batches=2, **step_options):
   return {k: v.clone() for k, v in dp.grads.items()}, state, dp.visible.clone()
 
 
+@pytest.mark.parametrize("sharded", [True, False])
 @pytest.mark.parametrize("culled", [False, True])
-def test_dense_exchange_on_one_rank_equals_the_sequential_loop(one_rank_group, culled):
+def test_dense_exchange_on_one_rank_equals_the_sequential_loop(one_rank_group, culled, sharded):
   g, cams = _scene(culled)
   want_g, want_s, want_v = _run(g, cams)                                  # no exchange: the reference's own loop
-  got_g, got_s, got_v = _run(g, cams, exchange_when_single=True)          # dense blocks through RCCL (one rank)
+  got_g, got_s, got_v = _run(g, cams, exchange_when_single=True, sharded_replay=sharded)   # through RCCL (one rank)
   for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view"):
     assert torch.equal(getattr(got_s, f), getattr(want_s, f)), f          # what the densify masks are made of: bit-exact
   assert torch.allclose(got_s.visibility, want_s.visibility, rtol=1e-6, atol=1e-7)
@@ -130,3 +133,50 @@ def test_dp_pack_and_replay_match_their_cpu_forms():
   assert torch.equal(states[0].visibility, states[1].visibility.cpu())
   for f in ("split_score", "prune_cost", "max_scale_px"):
     assert torch.allclose(getattr(states[0], f), getattr(states[1], f).cpu(), rtol=2e-5, atol=2e-6), f   # expf/logf: host libm vs device
+
+
+def test_sharded_pack_replay_finish_match_their_cpu_forms():
+  """densify.dp_pack_sharded / dp_replay_slice / dp_finish (the sharded exchange's three launches) against their torch
+  forms, with 4 ranks' worth of slices, two camera slots per rank and a point count that does not divide evenly."""
+  n, G, cpr = 1003, 4, 2
+  L = dp_slice_len(n, G)
+  gen = torch.Generator().manual_seed(4)
+  cams = []
+  for c in range(3):                                                        # cameras 0, 1, 2 of slot 0 / 1 (one slot unused)
+    m = 500 + 100 * c
+    idx = torch.randperm(n, generator=gen)[:m].sort().values
+    vis = torch.rand(m, generator=gen)
+    vis[::4] = 0.0
+    cams.append(dict(idx=idx, dcol=torch.randn(m, 3, generator=gen), split=torch.rand(m, generator=gen),
+                     prune=torch.rand(m, generator=gen), scale=torch.rand(m, 2, generator=gen) * 30,
+                     cam=torch.randn(3, generator=gen), vis=vis))
+  full = dict(idx=torch.arange(n), dcol=torch.ones(n, 3), split=torch.full((n,), 0.5), prune=torch.full((n,), 0.25),
+              scale=torch.full((n, 2), 2.0), cam=torch.zeros(3), vis=torch.ones(n))
+  out = {}
+  for dev in ("cpu", "cuda"):
+    factors = torch.full((cpr, 3 * n + 3), 7.0, device=dev)                 # garbage: every float must be (re)written
+    scores = torch.full((G, cpr, 2, L), 7.0, device=dev)
+    smax, sums = torch.zeros(n, device=dev), torch.ones(2 * n, device=dev)
+    for slot, d in enumerate((cams[0], full)):
+      dp_pack_sharded(factors[slot], scores, smax, n, slot, d["idx"].to(dev), d["dcol"].to(dev), d["split"].to(dev),
+                      d["prune"].to(dev), d["scale"].to(dev), d["cam"].to(dev), visibility=d["vis"].to(dev), sums=sums)
+    state = PointState.new_zeros(n, dev)
+    state.split_score.copy_(torch.linspace(-1, 1, n))
+    state.prune_cost.copy_(torch.linspace(2, 0, n))
+    gathered = torch.zeros(G, 2, L, device=dev)
+    for r in range(G):      # every "rank" replays its slice from the same send buffer (as if all ranks had sent this one)
+      recv = scores[r:r + 1].expand(G, cpr, 2, L).contiguous()
+      dp_replay_slice(state, recv, r, 2 * G, n, gathered[r])
+    dp_finish(state, gathered, n, scale_max=smax, sums=sums)
+    out[dev] = (factors, scores, smax, sums, state)
+  a, b = out["cpu"], out["cuda"]
+  # (padding cells behind point N of the last slice are never read: compare what carries points)
+  sc_a = a[1].permute(1, 2, 0, 3).reshape(cpr, 2, G * L)[:, :, :n]
+  sc_b = b[1].cpu().permute(1, 2, 0, 3).reshape(cpr, 2, G * L)[:, :, :n]
+  assert torch.equal(a[0], b[0].cpu()) and torch.equal(torch.nan_to_num(sc_a, nan=-1.0), torch.nan_to_num(sc_b, nan=-1.0))
+  assert torch.isnan(sc_a[0]).sum() == 2 * (n - 500) and not torch.isnan(sc_a[1]).any()
+  assert torch.equal(a[2], b[2].cpu()) and torch.equal(a[3], b[3].cpu())
+  assert torch.equal(a[4].points_in_view, b[4].points_in_view.cpu()) and torch.equal(a[4].max_scale_px, b[4].max_scale_px.cpu())
+  for f in ("split_score", "prune_cost", "visibility"):
+    assert torch.allclose(getattr(a[4], f), getattr(b[4], f).cpu(), rtol=2e-5, atol=2e-6), f        # expf/logf: host libm vs device
+  assert (a[4].split_score != torch.linspace(-1, 1, n)).all()               # every point was replayed (camera `full`)

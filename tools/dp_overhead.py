@@ -33,11 +33,17 @@ def fake_all_reduce(t, op=None, group=None, async_op=False):
   return _Done()
 
 
+def fake_all_to_all(out, inp, group=None, async_op=False):
+  out.copy_(inp)
+  return _Done()
+
+
 dist.is_initialized = lambda: True
 dist.get_world_size = lambda group=None: WORLD
 dist.get_rank = lambda group=None: 0
 dist.all_gather_into_tensor = fake_all_gather
 dist.all_reduce = fake_all_reduce
+dist.all_to_all_single = fake_all_to_all
 
 import splat_trainer_amd.distributed as D
 _exchange_counts = D.exchange_counts

@@ -287,7 +287,10 @@ int gsr_composite_forward(const float* rows /* [M,16] */, const uint32_t* sorted
                           int32_t* last_out, float* median_depth_out, float* vis_partial_out, float* pair_vis_out,
                           const GsrSegmentsC* segments_host /* or NULL */,
                           int32_t prefetch_rows /* speed only: touch the rows 32-64 pairs ahead of the walk (pays once the
-                                                   row table has outgrown the caches: GSR_PREFETCH_MIN_ROWS) */,
+                                                   row table has outgrown the caches: GSR_PREFETCH_MIN_ROWS).  With it
+                                                   the walk fetches sorted_splat four words at a time and may read up
+                                                   to THREE WORDS PAST the O-th entry (values unused): the buffer must be
+                                                   readable that far (gsr_frame_plan sizes it so) */,
                           void* stream);
 #ifndef GSR_PREFETCH_MIN_ROWS
 #define GSR_PREFETCH_MIN_ROWS 1000000

@@ -38,6 +38,8 @@ inline GsrRasterParams to_params(const GsrRasterParamsC* c) {
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+// four consecutive list words at an address that is only 4-byte aligned (a wave-uniform address: one s_load_dwordx4)
+struct __attribute__((packed, aligned(4))) Rank4 { uint32_t x, y, z, w; };
 #define GSR_V2(x) ((v2f){(x), (x)})
 
 // The VALU is the binding unit of both kernels (a wave64 fp32 op holds its SIMD for 4 cycles; only the packed
@@ -261,11 +263,12 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
   // PF instantiation (frames whose row table has outgrown the caches): the packed splat ids of the NEXT iteration's four
   // pairs arrive by one scalar load issued at the top of this iteration, so the row fetch of a pair no longer waits for
   // an index load issued just in front of it (one exposed scalar-load latency per pair; K6 653 -> 602 us at 3M splats;
-  // at 500k it costs 8 SGPRs and 8 %: 191 -> 206 us).  Reads up to 3 words past `end`, inside the list buffer: unused.
+  // at 500k it costs 8 SGPRs and 8 %: 191 -> 206 us).  Reads up to 3 words past `end` (values unused): the list buffer must
+  // be readable that far -- gsplat_hip.h states it for gsr_composite_forward(prefetch_rows = 1), gsr_frame_plan adds the slack.
   uint32_t rk[4] = {0u, 0u, 0u, 0u}, rk_next[4] = {0u, 0u, 0u, 0u};
   Splat nxt;
   if constexpr (PF) {
-    const uint4 q4 = *reinterpret_cast<const uint4*>(sorted_rank + begin);
+    const Rank4 q4 = *reinterpret_cast<const Rank4*>(sorted_rank + begin);
     rk[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.x); rk[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.y);
     rk[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.z); rk[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.w);
     nxt = load_splat_packed<C, MEDIAN>(rec, rk[0]);
@@ -276,7 +279,7 @@ __device__ __forceinline__ void fwd_walk(FwdPix<C>& px, const float* __restrict_
     if (PF && ((i - tile_start) & (GSR_K6_PREFETCH - 1)) == 0u) fwd_prefetch_step<C>(px, rec, sorted_rank, i, pf_end, lane);
     if constexpr (PF) {
       if (i + 4 < end) {
-        const uint4 q4 = *reinterpret_cast<const uint4*>(sorted_rank + i + 4);
+        const Rank4 q4 = *reinterpret_cast<const Rank4*>(sorted_rank + i + 4);
         rk_next[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.x); rk_next[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.y);
         rk_next[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.z); rk_next[3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.w);
       }

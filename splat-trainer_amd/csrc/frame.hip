@@ -90,8 +90,8 @@ int gsr_frame_plan(const GsrFrameC* f, GsrFramePlanC* p) {
   p->vals_b = out.take(4 * N);
   p->tvals_a = out.take(4 * cap);              // sorted instance ids / splat ids end up in the a or the b set
   p->tvals_b = out.take(4 * cap);
-  p->trank_a = out.take(4 * cap);
-  p->trank_b = out.take(4 * cap);
+  p->trank_a = out.take(4 * cap + 16);         // (+ 3 words: K6's large-frame walk fetches list words four at a time)
+  p->trank_b = out.take(4 * cap + 16);
   p->pair_vis = vis_partial ? out.take(4 * cap) : -1;
   // segment tables and pixel slots (forward checkpoints read by the backward pass)
   p->seg_capacity = 0;

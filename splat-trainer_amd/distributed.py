@@ -182,7 +182,7 @@ def gather_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: 
   N = num_points
   if visible_max is None:
     mine = torch.zeros(cameras_per_rank, N + 1, 3, dtype=torch.float32, device=dev)
-    for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
+    for slot, (idx, dcol, cam, *_) in zip(camera_slots, collector.items):
       mine[slot].index_copy_(0, idx, dcol)
       mine[slot, N].copy_(cam)
     if ws == 1:
@@ -193,7 +193,7 @@ def gather_sh_factors(collector, camera_slots: Sequence[int], cameras_per_rank: 
   # packed: field-major (4, visible_max + 1); entry 0 of every field is the header [count | camera x, y, z]
   L = int(visible_max) + 1
   mine = torch.zeros(cameras_per_rank, 4, L, dtype=torch.float32, device=dev)
-  for slot, (idx, dcol, cam) in zip(camera_slots, collector.items):
+  for slot, (idx, dcol, cam, *_) in zip(camera_slots, collector.items):
     m = idx.shape[0]
     if m > visible_max:
       raise ValueError(f"camera with {m} visible rows but visible_max = {visible_max}")
@@ -362,6 +362,20 @@ def exchange_point_scores(state, local: List[dict], num_cameras: int, num_points
   return state
 
 
+def position_term_done(collector, K: int) -> bool:
+  """Has the position term of the colour gradient been added to the position gradient by the local backward passes
+  (render_gaussians' fused node does, from the Jacobian its forward pass saved), or is it left to the multi-camera
+  rebuild (the three-call form: evaluate_sh_at hands on colour gradients only)?  Recorded per camera by the backward
+  node itself (ShFactorCollector.items[i][3]); every camera of every rank must have gone the same way."""
+  flags = {bool(it[3]) for it in collector.items if len(it) > 3}
+  if len(flags) > 1:
+    raise RuntimeError("the cameras of one batch mix call forms that add the colour gradient's position term locally with "
+                       "forms that leave it to the rebuild: use ONE form of the render call in render_backward")
+  if not flags:                       # this rank rendered nothing (or an older collector): the configured behaviour
+    return bool(collector.position_term_local) or K == 1
+  return flags.pop() or K == 1
+
+
 class CameraShardedStep:
   """One data-parallel batch of the hot path, the way bench.py and the tests run it: this rank renders and
   back-propagates ITS cameras of the batch (camera j -> rank j mod world) with the gradients accumulating straight into
@@ -392,8 +406,10 @@ class CameraShardedStep:
     ``position_term_local`` (default; factor exchange only): every rank adds the position term of its own cameras'
     colour gradient before the all-reduce -- ``render_gaussians(use_sh=True, sh_collector=...)`` does, from the Jacobian
     its forward pass saves -- and the multi-camera rebuild neither recomputes it for all cameras on every rank nor
-    reads the coefficient rows.  False: the rebuild adds it (needed when the callback uses the three-call form, whose
-    ``evaluate_sh_at`` hands on colour gradients only).  Must be the same on every rank."""
+    reads the coefficient rows.  False: the fused node does not save the Jacobian and the rebuild adds the term.  A
+    callback in the three-call form (``evaluate_sh_at`` hands on colour gradients only) needs no flag: every backward
+    node records whether it added the term (``position_term_done``) and the rebuild follows.  Every rank must run the
+    same form of the render call."""
     self.fused = bool(fused_grad_out)
     from .renderer import GradOut
     from .sh import ShFactorCollector
@@ -441,20 +457,28 @@ class CameraShardedStep:
       # Only the two sum columns are zero-filled: the first backward pass of the batch overwrites every row of the four
       # geometry gradients (and, when it is formed here, of the feature gradient) -- zeros where its camera saw nothing
       self.bucket.zero(except_views=(0, 1, 2, 3) if self.factor else (0, 1, 2, 3, 4))
-      self.grad_out.geometry_uninitialized = True
-      if not self.factor:
-        self.grad_out.feature_uninitialized = True
+      self.grad_out.begin_batch(geometry=True, feature=not self.factor)
     else:
       self.bucket.zero()
+      self.grad_out.begin_batch(geometry=False, feature=False)
     local = []
     if light and self.exchange and not dense:
       self.scale_max.zero_()
+    pack_now = dense and self.sharded
+    if pack_now:
+      self._sharded_begin(len(cameras))
     for j in mine:
       r = render_backward(j, cameras[j], self.grad_out, self.collector)
       if self.grad_out.geometry_uninitialized:
         raise RuntimeError("render_backward did not route grad_out into the renderer's backward pass (the gradient "
                            "buffers of this batch are uninitialised): pass grad_out on, or construct "
                            "CameraShardedStep(fused_grad_out=False)")
+      if pack_now:
+        # packed at once: nothing of the frame (its per-point outputs are views of the frame's whole output arena) has to
+        # stay alive until the end of the batch
+        self._sharded_pack(len(local), r.points)
+        local.append(j)
+        continue
       if dense:                               # sums ride in the all-reduce; scores + scale go into the camera's block
         local.append(dict(camera=j, idx=r.points.idx, split_score=r.points.split_score, prune_cost=r.points.prune_cost,
                           screen_scale=r.points.screen_scale, visibility=r.points.visibility))
@@ -469,16 +493,9 @@ class CameraShardedStep:
       self.bucket.extra[:N].index_add_(0, r.points.idx, r.points.visibility)      # mlp_scene.py:244
       if self.with_stats:
         local.append(point_stats_of(j, r.points))
-    # A slot whose flag is still set was never written (this rank had no camera in the batch, or none of its cameras
-    # reached that buffer): its share of the sum is zero -- and it must BE zero before a collective adds it to the others
-    if self.grad_out.geometry_uninitialized:
-      self.grad_out.geometry_uninitialized = False
-      for v in self.bucket.views[:4]:
-        v.zero_()
-    if self.grad_out.feature_uninitialized:
-      self.grad_out.feature_uninitialized = False
-      if self.grad_out.feature is not None:
-        self.grad_out.feature.zero_()
+    # A buffer no backward pass reached (this rank had no camera in the batch, or none of its cameras reached that buffer)
+    # holds nothing: its share of the sum is zero -- and it must BE zero before a collective adds it to the others
+    self.grad_out.finish_batch()
     if not self.exchange:
       return [] if light else local
     if dense:
@@ -491,7 +508,7 @@ class CameraShardedStep:
     if self.factor:
       pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True)
       exchange_sh_factors(self.collector, list(range(len(mine))), cpr, feature, position, self.feature_grad,
-                          None if self.collector.position_term_local else self.bucket.views[0], group=self.group,
+                          None if position_term_done(self.collector, feature.shape[2]) else self.bucket.views[0], group=self.group,
                           accumulate=False, after=pending,
                           visible_max=max(m for _, m in counts))
     else:
@@ -532,7 +549,7 @@ class CameraShardedStep:
     empty_f = torch.empty(0, dtype=torch.float32, device=dev)
     for s in range(cpr):
       if s < len(local):
-        d, (idx, d_colour, cam) = local[s], factors[s]
+        d, (idx, d_colour, cam, *_) = local[s], factors[s]
         dp_pack(send[s], N, idx, d_colour, d["split_score"], d["prune_cost"], d["screen_scale"], cam,
                 visibility=d.get("visibility"), sums=self.bucket.extra)
       else:
@@ -569,7 +586,7 @@ class CameraShardedStep:
     base = blocks.data_ptr()
     ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     # (every rank runs the same render path: the flag is the same everywhere; K = 1 has no position term at all)
-    position_done = self.collector.position_term_local or K == 1
+    position_done = position_term_done(self.collector, K)
     _lib.check(_lib.load().gsr_sh_backward_multi(C.c_void_p(base), width, C.c_void_p(base + 4 * 3 * N), width,
                                                  blocks.shape[0], ptr(feature.detach()), ptr(position.detach()), N, K,
                                                  ptr(self.feature_grad),
@@ -579,6 +596,32 @@ class CameraShardedStep:
     dp_replay(point_state, blocks, self.camera_slots(num_cameras, position.device), N, sums=self.bucket.extra)
 
   # ---------------------------------------------------------------------------------------- sharded exchange
+  def _sharded_begin(self, num_cameras: int):
+    """Send buffers of one batch: (cpr, 3 N + 3) colour-factor blocks and the (G, cpr, 2, L) score slices."""
+    from .densify import dp_slice_len
+    position = self.params[0]
+    N, dev = position.shape[0], position.device
+    cpr = (num_cameras + self.world - 1) // self.world
+    L = dp_slice_len(N, self.world)
+    self._send = (torch.empty(cpr, 3 * N + 3, dtype=torch.float32, device=dev),
+                  torch.empty(self.world, cpr, 2, L, dtype=torch.float32, device=dev), cpr, L)
+    self.scale_max.zero_()
+
+  def _sharded_pack(self, slot: int, points):
+    """Camera ``slot`` of this rank into the send buffers (``points`` None: an empty camera), right behind its backward
+    pass; also adds the camera to the two sum columns the gradient all-reduce carries."""
+    from .densify import dp_pack_sharded
+    factors, scores, cpr, L = self._send
+    N, dev = self.params[0].shape[0], self.params[0].device
+    if points is None:
+      e_i, e_f = torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float32, device=dev)
+      dp_pack_sharded(factors[slot], scores, self.scale_max, N, slot, e_i, e_f.view(0, 3), e_f, e_f, e_f.view(0, 2),
+                      torch.zeros(3, dtype=torch.float32, device=dev))
+      return
+    idx, d_colour, cam = self.collector.items[slot][:3]
+    dp_pack_sharded(factors[slot], scores, self.scale_max, N, slot, idx, d_colour, points.split_score, points.prune_cost,
+                    points.screen_scale, cam, visibility=points.visibility, sums=self.bucket.extra)
+
   def _exchange_sharded(self, num_cameras: int, local: List[dict], point_state):
     """The default exchange since round 4.  Per batch, G ranks, ``cpr`` camera slots per rank, L = ceil(N / G):
 
@@ -595,27 +638,15 @@ class CameraShardedStep:
     floats per camera instead of 6 N, and the replay costs N / G instead of N point-visits per camera."""
     import ctypes as C
     from . import _lib
-    from .densify import dp_finish, dp_pack_sharded, dp_replay_slice, dp_slice_len
+    from .densify import dp_finish, dp_replay_slice
     position, feature = self.params[0], self.params[4]
     N, K, dev = position.shape[0], feature.shape[2], position.device
     G = self.world
-    cpr = (num_cameras + G - 1) // G
-    L = dp_slice_len(N, G)
     live = dist.is_available() and dist.is_initialized()
-    factors = torch.empty(cpr, 3 * N + 3, dtype=torch.float32, device=dev)
-    scores = torch.empty(G, cpr, 2, L, dtype=torch.float32, device=dev)
-    self.scale_max.zero_()
-    empty_i = torch.empty(0, dtype=torch.int64, device=dev)
-    empty_f = torch.empty(0, dtype=torch.float32, device=dev)
-    items = self.collector.items
-    for s in range(cpr):
-      if s < len(local):
-        d, (idx, d_colour, cam) = local[s], items[s]
-        dp_pack_sharded(factors[s], scores, self.scale_max, N, s, idx, d_colour, d["split_score"], d["prune_cost"],
-                        d["screen_scale"], cam, visibility=d.get("visibility"), sums=self.bucket.extra)
-      else:                                  # an unused slot carries an empty camera: zero gradient, NaN scores
-        dp_pack_sharded(factors[s], scores, self.scale_max, N, s, empty_i, empty_f.view(0, 3), empty_f, empty_f,
-                        empty_f.view(0, 2), torch.zeros(3, dtype=torch.float32, device=dev))
+    factors, scores, cpr, L = self._send
+    for s in range(len(local), cpr):         # an unused slot carries an empty camera: zero gradient, NaN scores
+      self._sharded_pack(s, None)
+    self._send = None
     # (the packs above also added this rank's cameras to the two sum columns the gradient all-reduce carries)
     pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True, even_single=True) if live else None
     pending_max = dist.all_reduce(self.scale_max, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if live else None
@@ -640,7 +671,7 @@ class CameraShardedStep:
     width = blocks.shape[1]
     base = blocks.data_ptr()
     ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-    position_done = self.collector.position_term_local or K == 1
+    position_done = position_term_done(self.collector, K)
     if blocks.is_cuda:
       _lib.check(_lib.load().gsr_sh_backward_multi(C.c_void_p(base), width, C.c_void_p(base + 4 * 3 * N), width,
                                                    blocks.shape[0], ptr(feature.detach()), ptr(position.detach()), N, K,

@@ -201,42 +201,120 @@ def _start_readback(words: torch.Tensor):
 
 
 class GradOut:
-  """Optional fused gradient accumulation.  When given to project_to_image / evaluate_sh_at / render_gaussians,
-  the backward kernels add ("+=") their rows straight into these N-sized buffers -- typically the parameters'
-  ``.grad`` tensors, which is where the reference accumulates over the cameras of a batch
-  (trainer.py:500-514, mlp_scene.py:155-161) -- and autograd receives no gradient for those inputs.  This
-  removes the zero-fill + dense add of N-sized temporaries per camera.  Default (None): plain autograd.
+  """Optional fused gradient accumulation, and the ONE owner of the "who initialises which buffer" question.
 
-  ``feature_uninitialized = True`` tells the next SH backward that ``feature`` (by far the largest buffer, 3K of the
-  3K+11 floats per splat) holds nothing worth keeping: it is then overwritten row for row -- zeros where the camera saw
-  nothing -- instead of zero-filled by the caller and added to, and the flag is cleared.  Set it before the first
-  camera of a batch and skip ``feature`` in the zero-fill.  ``geometry_uninitialized = True`` says the same of the four
-  geometry buffers (position, log_scaling, rotation, alpha_logit): the next backward pass writes every row of them --
-  zeros where its camera saw nothing -- and clears the flag, so a batch needs no zero-fill of its gradient buffers and
-  its first camera no read-modify-write."""
+  When given to project_to_image / evaluate_sh_at / render_gaussians, the backward kernels add ("+=") their rows straight
+  into these N-sized buffers -- typically the parameters' ``.grad`` tensors, which is where the reference accumulates over
+  the cameras of a batch (trainer.py:500-514, mlp_scene.py:155-161) -- and autograd receives no gradient for those inputs.
+  This removes the zero-fill + dense add of N-sized temporaries per camera.  Default (None): plain autograd.
+
+  A batch may declare buffers UNINITIALISED (``begin_batch``, or the two constructor flags): their contents are not worth
+  keeping, so the first backward node that reaches one may overwrite every row of it (zeros where its camera saw nothing)
+  instead of the caller zero-filling it and the node reading it back -- ``feature`` is by far the largest buffer (3K of the
+  3K + 11 floats per splat).  Which node that is depends on autograd's order (the SH node of the three-call form runs
+  BEFORE the projection's, and only ADDS its position term), so the nodes do not test flags themselves; they ask:
+
+    ``claim_overwrite(node, names)``   "I write every row of these buffers."  True: all of them were uninitialised and are
+                                       now this node's to overwrite.  False: at least one holds earlier terms -- the ones
+                                       still uninitialised are zero-filled here and the node accumulates into all.
+    ``claim_accumulate(node, names)``  "I add to these buffers."  Those still uninitialised are zero-filled first.
+    ``finish_batch()``                 Whoever consumes the gradients (optimizer step, all-reduce) calls it: buffers no node
+                                       reached (a rank without a camera) are zero-filled; returns their names.
+
+  ``debug=True`` (or GSPLAT_HIP_DEBUG_GRADOUT=1) records every claim in ``log`` -- (node, action, buffers) in backward
+  order -- and raises on a protocol violation: a buffer overwritten after it had been written in the same batch, or a
+  buffer consumed (``finish_batch``) that a node had claimed for overwrite but some other node then also overwrote.
+  ``geometry_uninitialized`` / ``feature_uninitialized`` remain as properties over the same state (older callers set them)."""
+
+  GEOMETRY = ("position", "log_scaling", "rotation", "alpha_logit")
+  NAMES = GEOMETRY + ("feature",)
 
   def __init__(self, position=None, log_scaling=None, rotation=None, alpha_logit=None, feature=None,
-               feature_uninitialized: bool = False, geometry_uninitialized: bool = False):
+               feature_uninitialized: bool = False, geometry_uninitialized: bool = False, debug: Optional[bool] = None):
     self.position, self.log_scaling, self.rotation = position, log_scaling, rotation
     self.alpha_logit, self.feature = alpha_logit, feature
-    self.feature_uninitialized = feature_uninitialized
-    self.geometry_uninitialized = geometry_uninitialized
+    self.debug = (os.environ.get("GSPLAT_HIP_DEBUG_GRADOUT", "0") == "1") if debug is None else bool(debug)
+    self._fresh = set()                   # buffers declared uninitialised that no node has written yet
+    self._overwritten = {}                # debug: buffer -> node that overwrote it in this batch
+    self.log = []
+    self.begin_batch(geometry=geometry_uninitialized, feature=feature_uninitialized)
+
+  # ---- declaration / consumption (the caller's side)
+  def begin_batch(self, geometry: bool = True, feature: bool = True):
+    """Declares the four geometry buffers and / or ``feature`` uninitialised for the batch that starts now."""
+    self._fresh = set(self.GEOMETRY if geometry else ()) | ({"feature"} if feature else set())
+    self._overwritten = {}
+    self.log = []
+    return self
+
+  def finish_batch(self):
+    """Zero-fills every buffer no backward node reached; returns their names (empty in the usual case)."""
+    left = sorted(self._fresh)
+    for n in left:
+      t = getattr(self, n)
+      if t is not None:
+        t.zero_()
+    if left:
+      self._note("finish_batch", "zero-fill", left)
+    self._fresh.clear()
+    return left
+
+  # ---- claims (the backward nodes' side)
+  def claim_overwrite(self, node: str, names) -> bool:
+    names = tuple(names)
+    fresh = [n for n in names if n in self._fresh]
+    if len(fresh) == len(names):
+      for n in names:
+        self._fresh.discard(n)
+        if self.debug:
+          if n in self._overwritten:
+            raise _lib.GsplatHipError(f"GradOut: {node} overwrites {n}, which {self._overwritten[n]} already wrote in this batch")
+          self._overwritten[n] = node
+      self._note(node, "overwrite", names)
+      return True
+    self.claim_accumulate(node, names)
+    return False
+
+  def claim_accumulate(self, node: str, names):
+    fresh = [n for n in names if n in self._fresh]
+    for n in fresh:
+      t = getattr(self, n)
+      if t is not None:
+        t.zero_()
+      self._fresh.discard(n)
+    if fresh:
+      self._note(node, "zero-fill", fresh)
+    self._note(node, "accumulate", tuple(names))
+    return fresh                          # (a node that was handed a buffer other than this object's own zero-fills that one itself)
+
+  def _note(self, node, action, names):
+    if self.debug:
+      self.log.append((node, action, tuple(names)))
+
+  # ---- the two flags older callers use, over the same state
+  @property
+  def geometry_uninitialized(self) -> bool:
+    return any(n in self._fresh for n in self.GEOMETRY)
+
+  @geometry_uninitialized.setter
+  def geometry_uninitialized(self, value: bool):
+    (self._fresh.update if value else self._fresh.difference_update)(self.GEOMETRY)
+
+  @property
+  def feature_uninitialized(self) -> bool:
+    return "feature" in self._fresh
+
+  @feature_uninitialized.setter
+  def feature_uninitialized(self, value: bool):
+    (self._fresh.add if value else self._fresh.discard)("feature")
 
   def take_geometry_uninitialized(self) -> bool:
-    """True once per batch when the caller declared the four geometry buffers uninitialised: the backward pass that
-    sees it must leave every row defined (overwrite all of them, or zero-fill before adding)."""
-    flag, self.geometry_uninitialized = self.geometry_uninitialized, False
-    return flag
+    """= claim_overwrite over the four geometry buffers (kept for callers of the round-3 protocol)."""
+    return self.claim_overwrite("caller", self.GEOMETRY)
 
   def ensure_geometry_initialized(self):
-    """For a backward pass that only ADDS to a geometry buffer (the SH backward of the three-call form adds the colour
-    gradient's position term, and autograd runs it BEFORE the projection's backward): if the buffers are still declared
-    uninitialised, zero-fill them and clear the flag, so that nothing is added to garbage and the projection's backward
-    pass -- which would otherwise overwrite every row, the added term included -- accumulates instead."""
-    if self.take_geometry_uninitialized():
-      for t in (self.position, self.log_scaling, self.rotation, self.alpha_logit):
-        if t is not None:
-          t.zero_()
+    """= claim_accumulate over the four geometry buffers."""
+    self.claim_accumulate("caller", self.GEOMETRY)
 
   def _check(self, name, like):
     t = getattr(self, name)
@@ -301,9 +379,7 @@ class _ProjectFn(torch.autograd.Function):
     if go is not None:
       d_pos, d_ls = go._check("position", pos), go._check("log_scaling", ls)
       d_rot, d_al = go._check("rotation", rot), go._check("alpha_logit", al)
-      if go.take_geometry_uninitialized():
-        for t in (d_pos, d_ls, d_rot, d_al):
-          t.zero_()
+      go.claim_accumulate("project_to_image.backward", go.GEOMETRY)      # rows of `indexes` are added to; the rest must be defined
     else:
       live = M > 0 and (d_g2d is not None or d_depth is not None)
       alloc = torch.empty_like if (M == N and live) else torch.zeros_like   # every row is written when nothing was culled
@@ -654,11 +730,10 @@ class _FrameFn(torch.autograd.Function):
       d_pos, d_ls = go._check("position", pos), go._check("log_scaling", ls)
       d_rot, d_al = go._check("rotation", rot), go._check("alpha_logit", al)
       mode = 1
-      if go.take_geometry_uninitialized():
-        mode = 2 if dense else 0
-        if not dense:
-          for t in (d_pos, d_ls, d_rot, d_al):
-            t.zero_()
+      if dense and go.claim_overwrite("render_gaussians.backward", go.GEOMETRY):
+        mode = 2                           # every scene row written: no zero-fill, no read-modify-write
+      elif not dense:
+        go.claim_accumulate("render_gaussians.backward", go.GEOMETRY)
     else:
       alloc = torch.empty_like if dense else torch.zeros_like
       d_pos, d_ls, d_rot, d_al = alloc(pos), alloc(ls), alloc(rot), alloc(al)
@@ -668,14 +743,20 @@ class _FrameFn(torch.autograd.Function):
     d_sh, owner, sh_mode = None, None, 0
     if collector is None and want_sh:
       owner = sh_out[2] if (sh_out is not None and len(sh_out) > 2) else None
-      overwrite = sh_out is None or (owner is not None and owner.feature_uninitialized)
       d_sh = sh_out[0] if sh_out is not None else torch.empty(N, 3, K, dtype=torch.float32, device=dev)
-      if overwrite and dense:
-        sh_mode = 1              # every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no RMW
-      else:
-        sh_mode = 2              # rows of `indexes` accumulate
-        if overwrite:
+      if sh_out is None:
+        overwrite = True
+        if not dense:
           d_sh.zero_()
+      elif owner is None:
+        overwrite = False                  # caller-owned buffer without an owner object: plain accumulation
+      elif dense:
+        overwrite = owner.claim_overwrite("render_gaussians.backward", ("feature",))
+      else:
+        owner.claim_accumulate("render_gaussians.backward", ("feature",))
+        overwrite = False
+      # 1: every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no RMW; 2: rows of `indexes` accumulate
+      sh_mode = 1 if (overwrite and dense) else 2
     if N > 0:
       # the backward half of the frame behind ONE native call (csrc/frame.hip: gsr_frame_backward):
       # K7 -> packed gradient rows -> (scene row -> visible rank map) -> geometry sweep -> SH coefficient gradient
@@ -703,9 +784,9 @@ class _FrameFn(torch.autograd.Function):
     else:
       dcol = torch.zeros(0, 3, dtype=torch.float32, device=dev) if want_sh else None
     if collector is not None:              # data-parallel factor exchange: keep only the colour gradient
-      collector.items.append((indexes, dcol, cam))      # (position_term_local: the sweep above added the position term)
-    if owner is not None:
-      owner.feature_uninitialized = False
+      # (4th entry: has the position term of this camera's colour gradient been added to d_position already? -- by the
+      # sweep above, from the Jacobian the forward pass saved; K = 1 has no such term)
+      collector.items.append((indexes, dcol, cam, K == 1 or ctx.jac is not None))
     if go is not None:
       return (None, None, None, None, d_sh.to(ctx.in_dtypes[4]) if (d_sh is not None and sh_out is None) else None) + \
           nothing[5:]

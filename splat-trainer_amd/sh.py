@@ -28,7 +28,7 @@ class ShFactorCollector:
   gradient on every rank (csrc/geometry.hip: sh_bwd_multi_kernel)."""
 
   def __init__(self):
-    self.items = []            # (indexes (M,), d_colour (M,3), camera_pos (3,)) in the order backward ran
+    self.items = []            # (indexes (M,), d_colour (M,3), camera_pos (3,), position term added locally?) in backward order
     # Configuration, the same on every rank (distributed.CameraShardedStep sets it): True = every rank adds the position
     # term of its OWN cameras' colour gradient to the position gradient before the all-reduce (render_gaussians' fused
     # node does, from the Jacobian its forward pass saves), so the multi-camera rebuild leaves the position gradient
@@ -95,22 +95,32 @@ class _SHFn(torch.autograd.Function):
     M = idx.shape[0]
     go = ctx.grad_out
     if isinstance(go, ShFactorCollector):    # data-parallel factor exchange: keep only the colour gradient
-      if go.position_term_local and K > 1:
-        raise _lib.GsplatHipError("evaluate_sh_at cannot add the colour gradient's position term locally: use "
-                                  "render_gaussians(use_sh=True, sh_collector=...) or CameraShardedStep(position_term_local=False)")
-      go.items.append((idx, d_out.detach().to(torch.float32).contiguous(), cam))
+      # (4th entry False: this node hands on colour gradients only -- the position term of the colour gradient is left to
+      # the multi-camera rebuild, which the exchange then runs WITH the position gradient as a target; K = 1 has no term)
+      go.items.append((idx, d_out.detach().to(torch.float32).contiguous(), cam, K == 1))
       return None, None, None, None, None, None, None
     g = d_out.detach().to(torch.float32).contiguous() if M > 0 else None
     owner = go[2] if (go is not None and len(go) > 2) else None
-    overwrite = go is None or (owner is not None and owner.feature_uninitialized)
+    dense = N > 0 and (M == N or 8 * M >= N)
+    if go is None:
+      overwrite = True
+    elif owner is None:
+      overwrite = False
+    elif dense:
+      overwrite = owner.claim_overwrite("evaluate_sh_at.backward", ("feature",))
+    else:
+      # (too few visible rows for the dense overwrite: zero-fill + accumulate; a d_sh that is not the owner's own buffer
+      # -- grad_out=(d_sh, d_pos, owner) -- is zero-filled below)
+      overwrite = bool(owner.claim_accumulate("evaluate_sh_at.backward", ("feature",))) and owner.feature is not go[0]
     if go is not None:                       # fused "+=" into caller-owned buffers (see renderer.GradOut)
       d_sh, d_pos = go[0], go[1]
       if owner is not None and d_pos is not None and K > 1:
-        owner.ensure_geometry_initialized()  # this pass adds to d_pos and runs before the projection's backward pass
+        # this pass ADDS to d_pos and autograd runs it before the projection's backward pass
+        owner.claim_accumulate("evaluate_sh_at.backward", owner.GEOMETRY)
     else:
       d_sh = torch.empty(N, 3, K, dtype=torch.float32, device=pos.device)
       d_pos = torch.zeros_like(pos) if ctx.needs_input_grad[1] else None
-    if overwrite and N > 0 and (M == N or 8 * M >= N):
+    if overwrite and dense:
       # every row of d_sh is written (zeros where this camera saw nothing): no zero-fill, no read-modify-write
       inv = None
       if M < N:
@@ -124,8 +134,6 @@ class _SHFn(torch.autograd.Function):
       if M > 0:
         _lib.check(lib.gsr_sh_backward(_ptr(g), _ptr(sh), _ptr(pos), _ptr(idx), M, K, _ptr(cam), _ptr(ctx.jac),
                                        _ptr(d_sh), _ptr(d_pos), 1, _stream()), "gsr_sh_backward")
-    if owner is not None:
-      owner.feature_uninitialized = False
     if go is not None:
       return None, None, None, None, None, None, None
     return (d_sh.to(ctx.in_dtypes[0]), d_pos.to(ctx.in_dtypes[1]) if d_pos is not None else None,

@@ -84,7 +84,7 @@ typedef struct GsrSegmentsC {
 /* sizeof of the ABI's structs as the library was compiled: 0 GsrRasterParamsC, 1 GsrSegmentsC, 2 GsrFrameC,
  * 3 GsrFramePlanC, 4 GsrFrameResultC, 5 GsrFrameBackwardC (-1 otherwise) -- for a binding to check its own layout. */
 int64_t gsr_struct_bytes(int32_t which);
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 28) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 29) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -517,6 +517,20 @@ int gsr_point_state_add(const int64_t* idx, const float* screen_scale, int32_t s
                         const float* split_score, const float* prune_cost, int64_t M, float split_alpha,
                         float prune_alpha, float* state_prune_cost, float* state_split_score, float* state_max_scale_px,
                         int16_t* state_points_in_view, float* state_visibility, float* visible_sum, void* stream);
+
+/* The reference's per-camera loss mix (trainer.py:448-488 without reg_loss) behind one call per direction:
+ *   loss = w_l1 mean|x - t| + w_mse mean (x - t)^2 + w_ssim / levels * sum_l (1 - ssim_valid(pool^l x, pool^l t)),
+ * x = clamp(image, lo, hi), pool = 2 x 2 average pooling (floor sizes), image / target [H, W, C] contiguous, C <= 4,
+ * levels 1..4 (the coarsest level must be more than 10 pixels per side).  metrics_out (device floats): [loss, l1, mse,
+ * ssim_0 .. ssim_{levels-1}].  The workspace carries the forward pass's state to gsr_msloss_backward, which writes
+ * d_image = grad_scale_dev[0] * d loss / d image (zero where the clamp is active). */
+size_t gsr_msloss_workspace_bytes(int32_t H, int32_t W, int32_t C, int32_t levels);
+int gsr_msloss_forward(const float* image, const float* target, int32_t H, int32_t W, int32_t C, int32_t levels,
+                       float w_l1, float w_mse, float w_ssim, float lo, float hi, float* metrics_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int gsr_msloss_backward(const float* image, const float* target, int32_t H, int32_t W, int32_t C, int32_t levels,
+                        float w_l1, float w_mse, float w_ssim, float lo, float hi, const float* grad_scale_dev,
+                        void* workspace, size_t workspace_bytes, float* d_image, void* stream);
 
 /* ---- data-parallel exchange helpers (no reference counterpart: the reference is single-GPU) ------------- */
 /* One fixed-size block per camera, GSR_DP_BLOCK_FLOATS(N) = 6N + 3 floats: [0,3N) colour-gradient rows (0 where the

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -141,6 +141,9 @@ PROTOTYPES = {
     "gsr_ssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "gsr_ssim_forward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _sz, _p]),
     "gsr_ssim_backward": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    "gsr_msloss_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "gsr_msloss_forward": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _f, _f, _f, _f, _f, _p, _p, _sz, _p]),
+    "gsr_msloss_backward": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _f, _f, _f, _f, _f, _p, _p, _sz, _p, _p]),
     "gsr_select_workspace_bytes": (_sz, [_i64]),
     "gsr_select_n": (C.c_int, [_p, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "gsr_compact_workspace_bytes": (_sz, [_i64]),

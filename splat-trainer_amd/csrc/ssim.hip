@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
                                                        Strides st1, Strides st2, int C, int H, int W, int crop,
                                                        float C1, float C2, float inv_count, Gauss11 g,
                                                        float* __restrict__ block_sums, float* __restrict__ dm_dmu1,
-                                                       float* __restrict__ dm_dm11, float* __restrict__ dm_dm12) {
+                                                       float* __restrict__ dm_dm11, float* __restrict__ dm_dm12,
+                                                       float lo = -3.0e38f, float hi = 3.0e38f) {
   __shared__ float s_x[IN][IN + 1], s_y[IN][IN + 1];
   __shared__ float s_h[5][IN][TS + 1];
   __shared__ float s_red[4];
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
     const int ly = i / IN, lx = i % IN;
     const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
     const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    s_x[ly][lx] = in ? p1[gy * st1.sH + gx * st1.sW] : 0.f;
+    s_x[ly][lx] = in ? fminf(fmaxf(p1[gy * st1.sH + gx * st1.sW], lo), hi) : 0.f;     // (img1 clamped at load: fused loss)
     s_y[ly][lx] = in ? p2[gy * st2.sH + gx * st2.sW] : 0.f;
   }
   __syncthreads();
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
                                                        Gauss11 g, const float* __restrict__ dm_dmu1,
                                                        const float* __restrict__ dm_dm11,
                                                        const float* __restrict__ dm_dm12,
-                                                       const float* __restrict__ gscale_dev, float* __restrict__ dimg1) {
+                                                       const float* __restrict__ gscale_dev, float* __restrict__ dimg1,
+                                                       float lo = -3.0e38f, float hi = 3.0e38f) {
   __shared__ float s_in[3][IN][IN + 1];
   __shared__ float s_h[3][IN][TS + 1];
   const int plane = blockIdx.z, b = plane / C, c = plane % C;
@@ -190,12 +192,12 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     }
   }
   if (gx >= W) return;
-  const float gs = gscale_dev[0];
+  const float gs = gscale_dev ? gscale_dev[0] : 1.f;
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     const int gy = y0 + tg * 4 + o;
     if (gy >= H) continue;
-    const float x = img1[b * st1.sB + c * st1.sC + gy * st1.sH + gx * st1.sW];
+    const float x = fminf(fmaxf(img1[b * st1.sB + c * st1.sC + gy * st1.sH + gx * st1.sW], lo), hi);
     const float y = img2[b * st2.sB + c * st2.sC + gy * st2.sH + gx * st2.sW];
     dimg1[b * sto.sB + c * sto.sC + gy * sto.sH + gx * sto.sW] = gs * (acc[o][0] + 2.f * x * acc[o][1] + y * acc[o][2]);
   }
@@ -271,6 +273,208 @@ __global__ __launch_bounds__(PL_THREADS) void pixel_loss_bwd_kernel(const float*
   }
 }
 
+// ---- the reference's loss mix in one native call per direction (splat_trainer/trainer/trainer.py:448-488, without
+// reg_loss):   loss = w_l1 mean|x - t| + w_mse mean (x - t)^2 + w_ssim / L * sum_l (1 - ssim(pool^l x, pool^l t)),
+// x = clamp(image, lo, hi) (the scene's post-activation, mlp_scene.py:421-423), pool = F.avg_pool2d(kernel 2, stride 2).
+// As torch ops around fused_ssim that is ~60 launches per camera (clamp, 6 poolings and their 3 backward passes, two
+// pixel losses, a dozen scalar combinations and four strided copies): +0.55 ms on c2's 0.91 ms step.  Here:
+//   forward   msloss_pyramid (one pass over image and target: the pooled levels of both + the L1 / MSE partial sums)
+//             -> ssim_fwd per level (level 0 clamps at load) -> msloss_finish (all means, the loss, the logged metrics)
+//   backward  ssim_bwd per level (level 0 straight into d_image) -> msloss_combine (one pass: pixel terms, the levels'
+//             gradients through the poolings, the clamp's mask, the upstream scale).
+constexpr int ML_MAX_LEVELS = 4;
+
+struct MsLevels {
+  int n;                               // number of levels (1 .. 4)
+  int H[ML_MAX_LEVELS], W[ML_MAX_LEVELS];
+  float* pred[ML_MAX_LEVELS];          // [H_l, W_l, C] pooled clamped prediction (level 0: NULL, read from the image)
+  float* targ[ML_MAX_LEVELS];
+  float* dlev[ML_MAX_LEVELS];          // [H_l, W_l, C] d mean_ssim_l / d pred_l (level 0: the output image itself)
+};
+
+// thread = (8 x 8 block of level-0 pixels, channel): 2^(levels-1) <= 8.  Levels beyond `n` are not written.
+__global__ __launch_bounds__(256) void msloss_pyramid_kernel(const float* __restrict__ image,
+                                                             const float* __restrict__ target, int C, MsLevels lv,
+                                                             float lo, float hi, float* __restrict__ block_l1,
+                                                             float* __restrict__ block_mse) {
+  __shared__ float s_a[4], s_b[4];
+  const int H = lv.H[0], W = lv.W[0];
+  const int bw = (W + 7) / 8, bh = (H + 7) / 8;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float l1 = 0.f, mse = 0.f;
+  if (id < (int64_t)bw * bh * C) {
+    const int c = (int)(id % C);
+    const int bx = (int)((id / C) % bw), by = (int)(id / ((int64_t)C * bw));
+    float x1[4][4], t1[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sx = 0.f, st = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int y = by * 8 + 2 * j + dy, x = bx * 8 + 2 * i + dx;
+            if (y < H && x < W) {
+              const int64_t o = ((int64_t)y * W + x) * C + c;
+              const float xv = fminf(fmaxf(image[o], lo), hi), tv = target[o];
+              const float d = xv - tv;
+              l1 += fabsf(d);
+              mse += d * d;
+              sx += xv; st += tv;
+            }
+          }
+        x1[j][i] = 0.25f * sx; t1[j][i] = 0.25f * st;
+        const int y1 = by * 4 + j, xq = bx * 4 + i;
+        if (lv.n > 1 && y1 < lv.H[1] && xq < lv.W[1]) {
+          const int64_t o = ((int64_t)y1 * lv.W[1] + xq) * C + c;
+          lv.pred[1][o] = x1[j][i]; lv.targ[1][o] = t1[j][i];
+        }
+      }
+    if (lv.n > 2) {
+      float x2[2][2], t2[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          x2[j][i] = 0.25f * ((x1[2 * j][2 * i] + x1[2 * j][2 * i + 1]) + (x1[2 * j + 1][2 * i] + x1[2 * j + 1][2 * i + 1]));
+          t2[j][i] = 0.25f * ((t1[2 * j][2 * i] + t1[2 * j][2 * i + 1]) + (t1[2 * j + 1][2 * i] + t1[2 * j + 1][2 * i + 1]));
+          const int y2 = by * 2 + j, xq = bx * 2 + i;
+          if (y2 < lv.H[2] && xq < lv.W[2]) {
+            const int64_t o = ((int64_t)y2 * lv.W[2] + xq) * C + c;
+            lv.pred[2][o] = x2[j][i]; lv.targ[2][o] = t2[j][i];
+          }
+        }
+      if (lv.n > 3 && by < lv.H[3] && bx < lv.W[3]) {
+        const int64_t o = ((int64_t)by * lv.W[3] + bx) * C + c;
+        lv.pred[3][o] = 0.25f * ((x2[0][0] + x2[0][1]) + (x2[1][0] + x2[1][1]));
+        lv.targ[3][o] = 0.25f * ((t2[0][0] + t2[0][1]) + (t2[1][0] + t2[1][1]));
+      }
+    }
+  }
+  l1 = gsr_wave_sum(l1);
+  mse = gsr_wave_sum(mse);
+  if (gsr_lane() == 0) { s_a[threadIdx.x >> 6] = l1; s_b[threadIdx.x >> 6] = mse; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    block_l1[blockIdx.x] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+    block_mse[blockIdx.x] = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+  }
+}
+
+struct MsSums {
+  const float* ssim[ML_MAX_LEVELS];   // per-level block partials of the SSIM map
+  int ssim_n[ML_MAX_LEVELS];
+  float ssim_inv[ML_MAX_LEVELS];
+  const float* l1;
+  const float* mse;
+  int pix_n;
+  float pix_inv;
+};
+
+// metrics_out: [loss, l1, mse, ssim_0 .. ssim_{L-1}]  (what the reference logs with .item(), trainer.py:466-481)
+__global__ __launch_bounds__(256) void msloss_finish_kernel(MsSums sm, int levels, float w_l1, float w_mse, float w_ssim,
+                                                            float* __restrict__ metrics_out) {
+  __shared__ float s_red[4];
+  float vals[2 + ML_MAX_LEVELS];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < sm.pix_n; i += 256) a += sm.l1[i];
+  vals[0] = block_sum_256(a, s_red) * sm.pix_inv;
+  __syncthreads();
+  a = 0.f;
+  for (int i = threadIdx.x; i < sm.pix_n; i += 256) a += sm.mse[i];
+  vals[1] = block_sum_256(a, s_red) * sm.pix_inv;
+  __syncthreads();
+  float ssim_loss = 0.f;
+  for (int l = 0; l < levels; ++l) {
+    a = 0.f;
+    for (int i = threadIdx.x; i < sm.ssim_n[l]; i += 256) a += sm.ssim[l][i];
+    vals[2 + l] = block_sum_256(a, s_red) * sm.ssim_inv[l];
+    __syncthreads();
+    ssim_loss += 1.f - vals[2 + l];
+  }
+  if (threadIdx.x == 0) {
+    metrics_out[0] = vals[0] * w_l1 + vals[1] * w_mse + (ssim_loss / (float)levels) * w_ssim;
+    for (int k = 0; k < 2 + levels; ++k) metrics_out[1 + k] = vals[k];
+  }
+}
+
+// d_image holds d mean_ssim_0 / d x on entry (ssim_bwd of level 0 wrote it) and the loss gradient on exit.
+__global__ __launch_bounds__(256) void msloss_combine_kernel(const float* __restrict__ image,
+                                                             const float* __restrict__ target, int C, MsLevels lv,
+                                                             float lo, float hi, float w_l1, float w_mse, float w_ssim,
+                                                             const float* __restrict__ up, float* __restrict__ d_image) {
+  const int H = lv.H[0], W = lv.W[0];
+  const int64_t n = (int64_t)H * W * C;
+  const float inv_n = 1.f / (float)n, gs = up[0], cs = -w_ssim / (float)lv.n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float xv = image[i];
+    if (!(xv >= lo && xv <= hi)) { d_image[i] = 0.f; continue; }     // torch.clamp backward: inclusive on both ends
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int x = (int)(p % W), y = (int)(p / W);
+    const float d = xv - target[i];
+    float g = w_l1 * inv_n * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + w_mse * inv_n * 2.f * d;
+    float s = d_image[i], sc = 0.25f;
+#pragma unroll
+    for (int l = 1; l < ML_MAX_LEVELS; ++l) {
+      if (l < lv.n) {
+        const int yl = y >> l, xl = x >> l;
+        if (yl < lv.H[l] && xl < lv.W[l]) s += sc * lv.dlev[l][((int64_t)yl * lv.W[l] + xl) * C + c];
+        sc *= 0.25f;
+      }
+    }
+    d_image[i] = gs * (g + cs * s);
+  }
+}
+
+struct MsPlan {                 // byte offsets into the workspace
+  MsLevels lv;
+  size_t maps[ML_MAX_LEVELS];   // three [C, H_l, W_l] derivative maps per level, back to back
+  size_t sums[ML_MAX_LEVELS];   // SSIM block partials per level
+  int sums_n[ML_MAX_LEVELS];
+  size_t pix_l1, pix_mse;
+  int pix_blocks;
+  size_t total;
+};
+
+MsPlan ms_plan(int H, int W, int C, int levels, uint8_t* base) {
+  MsPlan p;
+  size_t at = 0;
+  auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) / 256 * 256; return o; };
+  p.lv.n = levels;
+  int h = H, w = W;
+  for (int l = 0; l < ML_MAX_LEVELS; ++l) {
+    p.lv.H[l] = p.lv.W[l] = 0;
+    p.lv.pred[l] = p.lv.targ[l] = p.lv.dlev[l] = nullptr;
+    p.maps[l] = p.sums[l] = 0; p.sums_n[l] = 0;
+    if (l >= levels) continue;
+    if (l > 0) { h /= 2; w /= 2; }
+    p.lv.H[l] = h; p.lv.W[l] = w;
+    const size_t plane = (size_t)h * w * C * sizeof(float);
+    if (l > 0) {
+      p.lv.pred[l] = reinterpret_cast<float*>(base + take(plane));
+      p.lv.targ[l] = reinterpret_cast<float*>(base + take(plane));
+      p.lv.dlev[l] = reinterpret_cast<float*>(base + take(plane));
+    }
+    p.maps[l] = take(3 * plane);
+    p.sums_n[l] = ((w + TS - 1) / TS) * ((h + TS - 1) / TS) * C;
+    p.sums[l] = take((size_t)p.sums_n[l] * sizeof(float));
+  }
+  const int64_t work = (int64_t)((W + 7) / 8) * ((H + 7) / 8) * C;
+  p.pix_blocks = (int)((work + 255) / 256);
+  p.pix_l1 = take((size_t)p.pix_blocks * sizeof(float));
+  p.pix_mse = take((size_t)p.pix_blocks * sizeof(float));
+  p.total = at;
+  return p;
+}
+
+inline bool ms_args_ok(int H, int W, int C, int levels) {
+  if (H <= 0 || W <= 0 || C < 1 || C > 4 || levels < 1 || levels > ML_MAX_LEVELS) return false;
+  return (H >> (levels - 1)) > 10 && (W >> (levels - 1)) > 10;      // padding = "valid" needs more than 10 pixels per side
+}
+
 }  // namespace
 
 extern "C" {
@@ -327,6 +531,83 @@ int gsr_ssim_backward(const float* img1, const float* img2, const int64_t* strid
   const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, B * C);
   ssim_bwd_kernel<<<grid, 256, 0, stream>>>(img1, img2, s1, s2, so, C, H, W, make_gauss(), dm_dmu1, dm_dm11, dm_dm12,
                                            grad_scale_dev, d_img1);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+size_t gsr_msloss_workspace_bytes(int32_t H, int32_t W, int32_t C, int32_t levels) {
+  if (!ms_args_ok(H, W, C, levels)) return 256;
+  return ms_plan(H, W, C, levels, nullptr).total + 256;
+}
+
+// metrics_out: device floats [loss, l1, mse, ssim_0 .. ssim_{levels-1}].  The workspace keeps what the backward pass reads.
+int gsr_msloss_forward(const float* image, const float* target, int32_t H, int32_t W, int32_t C, int32_t levels,
+                       float w_l1, float w_mse, float w_ssim, float lo, float hi, float* metrics_out, void* workspace,
+                       size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!ms_args_ok(H, W, C, levels) || !image || !target || !metrics_out || !(lo <= hi)) return GSR_ERR_INVALID_ARGUMENT;
+  if (!workspace || workspace_bytes < gsr_msloss_workspace_bytes(H, W, C, levels)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  uint8_t* base = reinterpret_cast<uint8_t*>(workspace);
+  const MsPlan p = ms_plan(H, W, C, levels, base);
+  msloss_pyramid_kernel<<<p.pix_blocks, 256, 0, stream>>>(image, target, C, p.lv, lo, hi,
+                                                         reinterpret_cast<float*>(base + p.pix_l1),
+                                                         reinterpret_cast<float*>(base + p.pix_mse));
+  GSR_CHECK_LAUNCH();
+  const Gauss11 g = make_gauss();
+  MsSums sm;
+  for (int l = 0; l < ML_MAX_LEVELS; ++l) { sm.ssim[l] = nullptr; sm.ssim_n[l] = 0; sm.ssim_inv[l] = 0.f; }
+  for (int l = 0; l < levels; ++l) {
+    const int h = p.lv.H[l], w = p.lv.W[l];
+    const Strides st = {0, 1, (int64_t)w * C, C};                 // (H, W, C) image seen as one batch of C planes
+    const float* x = l ? p.lv.pred[l] : image;
+    const float* t = l ? p.lv.targ[l] : target;
+    const dim3 grid((w + TS - 1) / TS, (h + TS - 1) / TS, C);
+    const float inv_count = 1.f / ((float)C * (h - 10) * (float)(w - 10));
+    float* maps = reinterpret_cast<float*>(base + p.maps[l]);
+    const size_t plane = (size_t)h * w * C;
+    ssim_fwd_kernel<true><<<grid, 256, 0, stream>>>(x, t, st, st, C, h, w, 5, 0.01f * 0.01f, 0.03f * 0.03f, inv_count, g,
+                                                   reinterpret_cast<float*>(base + p.sums[l]), maps, maps + plane,
+                                                   maps + 2 * plane, l ? -3.0e38f : lo, l ? 3.0e38f : hi);
+    GSR_CHECK_LAUNCH();
+    sm.ssim[l] = reinterpret_cast<const float*>(base + p.sums[l]);
+    sm.ssim_n[l] = p.sums_n[l];
+    sm.ssim_inv[l] = inv_count;
+  }
+  sm.l1 = reinterpret_cast<const float*>(base + p.pix_l1);
+  sm.mse = reinterpret_cast<const float*>(base + p.pix_mse);
+  sm.pix_n = p.pix_blocks;
+  sm.pix_inv = 1.f / ((float)H * (float)W * (float)C);
+  msloss_finish_kernel<<<1, 256, 0, stream>>>(sm, levels, w_l1, w_mse, w_ssim, metrics_out);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+// d_image [H, W, C] = grad_scale_dev[0] * d loss / d image, from the workspace gsr_msloss_forward left.
+int gsr_msloss_backward(const float* image, const float* target, int32_t H, int32_t W, int32_t C, int32_t levels,
+                        float w_l1, float w_mse, float w_ssim, float lo, float hi, const float* grad_scale_dev,
+                        void* workspace, size_t workspace_bytes, float* d_image, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!ms_args_ok(H, W, C, levels) || !image || !target || !grad_scale_dev || !d_image) return GSR_ERR_INVALID_ARGUMENT;
+  if (!workspace || workspace_bytes < gsr_msloss_workspace_bytes(H, W, C, levels)) return GSR_ERR_WORKSPACE_TOO_SMALL;
+  uint8_t* base = reinterpret_cast<uint8_t*>(workspace);
+  const MsPlan p = ms_plan(H, W, C, levels, base);
+  const Gauss11 g = make_gauss();
+  for (int l = 0; l < levels; ++l) {
+    const int h = p.lv.H[l], w = p.lv.W[l];
+    const Strides st = {0, 1, (int64_t)w * C, C};
+    const float* x = l ? p.lv.pred[l] : image;
+    const float* t = l ? p.lv.targ[l] : target;
+    const float* maps = reinterpret_cast<const float*>(base + p.maps[l]);
+    const size_t plane = (size_t)h * w * C;
+    const dim3 grid((w + TS - 1) / TS, (h + TS - 1) / TS, C);
+    ssim_bwd_kernel<<<grid, 256, 0, stream>>>(x, t, st, st, st, C, h, w, g, maps, maps + plane, maps + 2 * plane, nullptr,
+                                             l ? p.lv.dlev[l] : d_image, l ? -3.0e38f : lo, l ? 3.0e38f : hi);
+    GSR_CHECK_LAUNCH();
+  }
+  const int64_t n = (int64_t)H * W * C;
+  const int64_t want = (n + 255) / 256;
+  msloss_combine_kernel<<<(int)(want < 16384 ? want : 16384), 256, 0, stream>>>(image, target, C, p.lv, lo, hi, w_l1, w_mse,
+                                                                              w_ssim, grad_scale_dev, d_image);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

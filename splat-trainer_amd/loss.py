@@ -124,24 +124,74 @@ def clamped_l1_loss(image: torch.Tensor, target: torch.Tensor, clamp=(0.0, 1.0))
   return _pixel_loss(image, target, 1, clamp)
 
 
+class _MSLossFn(torch.autograd.Function):
+  """The reference's loss mix behind one native call per direction (csrc/ssim.hip: gsr_msloss_forward / _backward)."""
+
+  @staticmethod
+  def forward(ctx, image, target, weights, levels, lo, hi):
+    lib = _lib.load()
+    x = image.detach()
+    t = target.detach()
+    H, W, Cc = x.shape
+    ws_bytes = lib.gsr_msloss_workspace_bytes(H, W, Cc, levels)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    metrics = torch.empty(3 + levels, dtype=torch.float32, device=x.device)
+    _lib.check(lib.gsr_msloss_forward(_ptr(x), _ptr(t), H, W, Cc, levels, weights[0], weights[1], weights[2], lo, hi,
+                                      _ptr(metrics), _ptr(ws), ws_bytes, _stream()), "gsr_msloss_forward")
+    ctx.save_for_backward(x, t, ws)
+    ctx.args = (weights, levels, lo, hi, ws_bytes)
+    ctx.mark_non_differentiable(metrics)
+    return metrics[0], metrics
+
+  @staticmethod
+  def backward(ctx, g, _g_metrics):
+    lib = _lib.load()
+    x, t, ws = ctx.saved_tensors
+    weights, levels, lo, hi, ws_bytes = ctx.args
+    H, W, Cc = x.shape
+    gs = g.detach().to(torch.float32).reshape(1).contiguous()
+    d = torch.empty_like(x)
+    _lib.check(lib.gsr_msloss_backward(_ptr(x), _ptr(t), H, W, Cc, levels, weights[0], weights[1], weights[2], lo, hi,
+                                       _ptr(gs), _ptr(ws), ws_bytes, _ptr(d), _stream()), "gsr_msloss_backward")
+    return d, None, None, None, None, None
+
+
 def reference_loss(image: torch.Tensor, target: torch.Tensor, l1_weight: float = 0.0, mse_weight: float = 10.0,
-                   ssim_weight: float = 1.0, ssim_levels: int = 4, clamp=(0.0, 1.0)) -> torch.Tensor:
+                   ssim_weight: float = 1.0, ssim_levels: int = 4, clamp=(0.0, 1.0), fused: bool = True,
+                   return_metrics: bool = False):
   """The reference's per-camera loss mix, ``Trainer.compute_losses`` without ``reg_loss`` (trainer.py:448-488): L1 and
   MSE of the image against the target, and the multi-scale SSIM loss -- ``fused_ssim(padding="valid")`` on the
   channels_last view of the (H, W, 3) image and on ``ssim_levels - 1`` successive 2 x 2 average poolings of it, the mean
   of the levels' ``1 - ssim`` -- each times its weight (defaults: config/trainer/default.yaml:52-54 for the weights,
   trainer/config.py:70 for the levels; all three terms are formed whatever their weight, as the reference does).
   ``image`` is the UNclamped rendering; the reference receives it clamped from ``MLPScene.render`` (mlp_scene.py:421-423),
-  which ``clamp`` restates.  The reference's ``.item()`` calls (logged metrics) are not part of the arithmetic."""
+  which ``clamp`` restates.  The reference's ``.item()`` calls (logged metrics) are not part of the arithmetic;
+  ``return_metrics`` also returns the device tensor [loss, l1, mse, ssim_0 .. ssim_{levels-1}] they would read.
+
+  ``fused`` (default): ONE native call per direction (pyramids of both images + the pixel losses in one pass, SSIM per
+  level, one combining pass back through the poolings and the clamp) instead of ~60 torch launches around fused_ssim;
+  needs a contiguous float32 (H, W, C <= 4) image, ``ssim_levels`` <= 4 and more than 10 pixels per side on the coarsest
+  level, else -- and with ``fused=False`` -- the composition below (the form the fused path is tested against)."""
   import torch.nn.functional as F
+  ok = (fused and clamp is not None and image.is_cuda and target.is_cuda and image.dim() == 3 and image.shape == target.shape and
+        image.dtype is torch.float32 and target.dtype is torch.float32 and image.is_contiguous() and target.is_contiguous() and
+        1 <= image.shape[2] <= 4 and 1 <= ssim_levels <= 4 and
+        min(image.shape[0], image.shape[1]) >> (ssim_levels - 1) > 10)
+  if ok:
+    loss, metrics = _MSLossFn.apply(image, target, (float(l1_weight), float(mse_weight), float(ssim_weight)),
+                                    int(ssim_levels), float(clamp[0]), float(clamp[1]))
+    return (loss, metrics) if return_metrics else loss
   l1 = clamped_l1_loss(image, target, clamp)
   mse = clamped_mse_loss(image, target, clamp)
   img = image.clamp(*clamp) if clamp is not None else image
   ref = target.unsqueeze(0).permute(0, 3, 1, 2)
   pred = img.unsqueeze(0).permute(0, 3, 1, 2)
-  loss = 1.0 - fused_ssim(pred, ref, padding="valid")
+  ssims = [fused_ssim(pred, ref, padding="valid")]
   for _ in range(1, ssim_levels):
     pred = F.avg_pool2d(pred, kernel_size=2, stride=2)
     ref = F.avg_pool2d(ref, kernel_size=2, stride=2)
-    loss = loss + (1.0 - fused_ssim(pred, ref, padding="valid"))
-  return l1 * l1_weight + mse * mse_weight + (loss / ssim_levels) * ssim_weight
+    ssims.append(fused_ssim(pred, ref, padding="valid"))
+  loss = l1 * l1_weight + mse * mse_weight + (sum(1.0 - s for s in ssims) / ssim_levels) * ssim_weight
+  if return_metrics:
+    return loss, torch.stack([loss.detach(), l1.detach(), mse.detach()] + [s.detach() for s in ssims])
+  return loss

@@ -153,16 +153,46 @@ def test_reference_loss_mix_matches_the_torch_expression():
   ref = torch.rand(H, W, 3)
   pred = ref + 0.1 * torch.randn(H, W, 3) + 0.05                       # some pixels leave [0, 1]
   for weights in (dict(l1_weight=0.0, mse_weight=10.0, ssim_weight=1.0, ssim_levels=4),
-                  dict(l1_weight=1.0, mse_weight=0.5, ssim_weight=0.2, ssim_levels=3)):
+                  dict(l1_weight=1.0, mse_weight=0.5, ssim_weight=0.2, ssim_levels=3),
+                  dict(l1_weight=0.3, mse_weight=2.0, ssim_weight=1.0, ssim_levels=4, fused=False),
+                  dict(l1_weight=0.3, mse_weight=2.0, ssim_weight=1.0, ssim_levels=1)):
     pd = pred.clone().cuda().requires_grad_(True)
-    got = sta.reference_loss(pd, ref.cuda(), **weights)
-    got.backward()
+    got, metrics = sta.reference_loss(pd, ref.cuda(), return_metrics=True, **weights)
+    (got * 1.5).backward()
+    weights = {k: v for k, v in weights.items() if k != "fused"}
     po = pred.clone().double().requires_grad_(True)
     img = po.clamp(0, 1)
     ssim_l, _ = ssim_oracle.multiscale_ssim_loss(img, ref.double(), levels=weights["ssim_levels"])
     want = (F.l1_loss(img, ref.double()) * weights["l1_weight"] + F.mse_loss(img, ref.double()) * weights["mse_weight"] +
             ssim_l * weights["ssim_weight"])
-    want.backward()
+    (want * 1.5).backward()
     assert abs(got.item() - want.item()) < 2e-6 * max(1.0, abs(want.item())), (got.item(), want.item())
     err = (pd.grad.cpu().double() - po.grad).abs().max().item() / po.grad.abs().max().item()
     assert err < 1e-4, err
+    # the metrics the reference logs with .item(): l1, mse and the full-resolution ssim
+    m = metrics.cpu().double()
+    assert abs(m[0] - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+    assert abs(m[1] - F.l1_loss(img, ref.double()).item()) < 2e-6 and abs(m[2] - F.mse_loss(img, ref.double()).item()) < 2e-6
+    assert abs(m[3] - ssim_oracle.fused_ssim(img.detach().unsqueeze(0).permute(0, 3, 1, 2), ref.double().unsqueeze(0).permute(0, 3, 1, 2), "valid").item()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(135, 181, 3), (97, 203, 1), (1080, 1920, 3)])
+def test_fused_reference_loss_equals_its_composition(shape):
+  """The one-call fused loss against the torch composition around fused_ssim (odd sizes: the poolings drop the last row /
+  column, 1080p: the bench's shape): value within 2e-6, gradient within 2e-5 of its largest entry, and two runs bit-equal."""
+  import splat_trainer_amd as sta
+  gen = torch.Generator(device="cuda").manual_seed(3)
+  ref = torch.rand(shape, device="cuda", generator=gen)
+  pred = ref + 0.1 * torch.randn(shape, device="cuda", generator=gen) + 0.03
+  levels = 4 if min(shape[0], shape[1]) >= 97 else 3
+  outs = []
+  for fused in (True, False, True):
+    p = pred.clone().requires_grad_(True)
+    loss = sta.reference_loss(p, ref, l1_weight=0.2, mse_weight=10.0, ssim_weight=1.0, ssim_levels=levels, fused=fused)
+    loss.backward()
+    outs.append((loss.detach(), p.grad))
+  assert abs(outs[0][0].item() - outs[1][0].item()) < 2e-6 * max(1.0, abs(outs[1][0].item()))
+  err = (outs[0][1] - outs[1][1]).abs().max().item() / outs[1][1].abs().max().item()
+  assert err < 2e-5, err
+  assert outs[0][0].item() == outs[2][0].item() and torch.equal(outs[0][1], outs[2][1])

@@ -3,8 +3,8 @@
 #   gpurun -- bash tools/pmc_extra.sh   -> prints per-launch means; kept under profiles/r03_pmc_extra_c2.txt
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmcx; mkdir -p gpurun_out/pmcx
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_BRANCH SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SALU SQ_INSTS_VALU --output-format csv -d gpurun_out/pmcx/a -- python3 bench.py --no-cpu-baseline --workload c2 --steps 3 --warmup 1 > gpurun_out/pmcx/a.log 2>&1 || echo "pass a failed"
-rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SMEM --output-format csv -d gpurun_out/pmcx/b -- python3 bench.py --no-cpu-baseline --workload c2 --steps 3 --warmup 1 > gpurun_out/pmcx/b.log 2>&1 || echo "pass b failed"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_BRANCH SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SALU SQ_INSTS_VALU --output-format csv -d gpurun_out/pmcx/a -- python3 bench.py --no-cpu-baseline --no-scale-workload --workload c2 --steps 3 --warmup 1 > gpurun_out/pmcx/a.log 2>&1 || echo "pass a failed"
+rocprofv3 --kernel-trace --pmc SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SMEM --output-format csv -d gpurun_out/pmcx/b -- python3 bench.py --no-cpu-baseline --no-scale-workload --workload c2 --steps 3 --warmup 1 > gpurun_out/pmcx/b.log 2>&1 || echo "pass b failed"
 python3 - <<'PY'
 import csv,glob,collections
 for p in ("a","b"):

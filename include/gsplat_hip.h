@@ -84,7 +84,7 @@ typedef struct GsrSegmentsC {
 /* sizeof of the ABI's structs as the library was compiled: 0 GsrRasterParamsC, 1 GsrSegmentsC, 2 GsrFrameC,
  * 3 GsrFramePlanC, 4 GsrFrameResultC, 5 GsrFrameBackwardC (-1 otherwise) -- for a binding to check its own layout. */
 int64_t gsr_struct_bytes(int32_t which);
-int gsr_abi_version(void);                 /* bumped on any signature change (currently 29) */
+int gsr_abi_version(void);                 /* bumped on any signature change (currently 30) */
 const char* gsr_error_string(int code);
 
 /* ---- device-wide primitives (K5: radix bin + depth sort) ------------------------------------------------ */
@@ -430,6 +430,10 @@ typedef struct GsrFrameBackwardC {
 } GsrFrameBackwardC;
 /* event_k7_begin / event_k7_end: hipEvent_t recorded around the composite backward launch, or NULL. */
 int gsr_frame_backward(const GsrFrameBackwardC* backward_host, void* event_k7_begin, void* event_k7_end, void* stream);
+/* The same in two halves: stages bit 0 = K7 + per-splat reduction (grad_rows complete behind it), bit 1 = the rest; 3 = all.
+ * A data-parallel caller packs and starts exchanging the colour-gradient factors (grad_rows columns 8..10) in between. */
+int gsr_frame_backward_stages(const GsrFrameBackwardC* backward_host, int32_t stages, void* event_k7_begin,
+                              void* event_k7_end, void* stream);
 
 /* ---- loss stage next to the path: fused SSIM, replaces the CUDA-only fused_ssim package
  *      the reference imports (splat_trainer/trainer/trainer.py:17,112,450-462; trainer/evaluation.py:7,42) ------------ */
@@ -557,7 +561,8 @@ int gsr_dp_replay(const float* blocks, int64_t stride, const int32_t* slots, int
  * camera's all-gather block, colour-gradient rows + camera position -- the input of gsr_sh_backward_multi); its two
  * controller scores in the all-to-all SEND layout scores_out[dest rank][slot][field][L] (field 0 split_score, 1
  * prune_cost; NaN where unseen); the running maximum of the larger screen-space sigma over this rank's cameras in
- * scale_max[N] (finished by a MAX all-reduce); and the two sums as gsr_dp_pack does.
+ * scale_max[N] (finished by a MAX all-reduce); and the two sums as gsr_dp_pack does.  factors_out may be NULL (the block
+ * was packed earlier by gsr_dp_pack_factors_rows).
  * gsr_dp_replay_slice applies the two exp_lerp EMAs (point_state.py:49-50) of ALL cameras of the batch in camera order
  * (camera c arrived from rank c % num_ranks in slot c / num_ranks: recv[src rank][slot][field][L]) to this rank's slice
  * of the state and leaves the slice's new values in slice_out[field][L], the all-gather send buffer.
@@ -567,6 +572,11 @@ int gsr_dp_pack_sharded(const int64_t* idx, const float* dL_dcolors, const float
                         const float* screen_scale, int32_t scale_cols, const float* camera_pos, int64_t M, int64_t N,
                         int32_t num_ranks, int32_t slots_per_rank, int32_t slot, float* factors_out, float* scores_out,
                         float* scale_max, const float* visibility, float* visibility_sum, float* views_sum, void* stream);
+/* factors_out (3N + 3) of one camera straight from its packed gradient rows [M,16] (columns 8..10 = d colour), i.e. before
+ * the backward sweep has copied them out: what lets the factor all-gather start behind gsr_frame_backward_stages(.., 1, ..).
+ * gsr_dp_pack_sharded(factors_out = NULL) then leaves the block alone. */
+int gsr_dp_pack_factors_rows(const int64_t* idx, const float* grad_rows, const float* camera_pos, int64_t M, int64_t N,
+                             float* factors_out, void* stream);
 int gsr_dp_replay_slice(const float* recv, int32_t num_ranks, int32_t slots_per_rank, int64_t N, int32_t rank,
                         int32_t num_cameras, float split_alpha, float prune_alpha, const float* state_split_score,
                         const float* state_prune_cost, float* slice_out, void* stream);

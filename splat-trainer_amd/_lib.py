@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GSPLAT_HIP_LIB: load another build of the same library (kernel experiments, tools/k67_bench.py); never a fallback
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(PKG_DIR, "libgsplat_hip.so")
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 PREFETCH_MIN_ROWS = 1_000_000      # include/gsplat_hip.h: GSR_PREFETCH_MIN_ROWS
 
 
@@ -159,6 +159,8 @@ PROTOTYPES = {
     "gsr_frame_plan": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC)]),
     "gsr_struct_bytes": (_i64, [_i32]),
     "gsr_frame_backward": (C.c_int, [C.POINTER(GsrFrameBackwardC), _p, _p, _p]),
+    "gsr_frame_backward_stages": (C.c_int, [C.POINTER(GsrFrameBackwardC), _i32, _p, _p, _p]),
+    "gsr_dp_pack_factors_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "gsr_frame_forward": (C.c_int, [C.POINTER(GsrFrameC), C.POINTER(GsrFramePlanC), _p, _p, C.POINTER(GsrFrameResultC), _p,
                                     _p, _p, _p, _p]),
     "gsr_reduce_visibility": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p]),

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(DN_THREADS) void dp_replay_kernel(const float* __re
 __global__ __launch_bounds__(DN_THREADS) void dp_fill_sharded_kernel(float* __restrict__ factors, float* __restrict__ scores,
                                                                      int64_t N, int64_t L, int32_t cpr, int32_t slot) {
   const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
-  if (i < 3 * N) factors[i] = 0.f;
+  if (factors && i < 3 * N) factors[i] = 0.f;
   if (i < N) {
     const int64_t r = i / L, o = i - r * L;
     float* cell = scores + ((r * cpr + slot) * 2) * L + o;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(DN_THREADS) void dp_pack_sharded_kernel(
     float* __restrict__ scale_max, const float* __restrict__ vis, float* __restrict__ vis_sum,
     float* __restrict__ views_sum) {
   const int64_t m = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
-  if (m < 3) factors[3 * N + m] = campos[m];
+  if (factors && m < 3) factors[3 * N + m] = campos[m];
   if (m >= M) return;
   const int64_t i = idx ? idx[m] : m;
   if (vis) {                                        // this rank's share of the two per-point SUMS (rows unique per camera)
@@ -334,9 +334,11 @@ __global__ __launch_bounds__(DN_THREADS) void dp_pack_sharded_kernel(
     vis_sum[i] += v;
     if (v > 0.f) views_sum[i] += 1.f;
   }
-  factors[3 * i] = dcol[3 * m];
-  factors[3 * i + 1] = dcol[3 * m + 1];
-  factors[3 * i + 2] = dcol[3 * m + 2];
+  if (factors) {
+    factors[3 * i] = dcol[3 * m];
+    factors[3 * i + 1] = dcol[3 * m + 1];
+    factors[3 * i + 2] = dcol[3 * m + 2];
+  }
   const int64_t r = i / L, o = i - r * L;
   float* cell = scores + ((r * cpr + slot) * 2) * L + o;
   cell[0] = split[m];
@@ -344,6 +346,23 @@ __global__ __launch_bounds__(DN_THREADS) void dp_pack_sharded_kernel(
   float sc = scale[m * scale_cols];
   if (scale_cols == 2) sc = fmaxf(sc, scale[m * 2 + 1]);
   scale_max[i] = fmaxf(scale_max[i], sc);           // over this rank's cameras; a MAX all-reduce finishes it
+}
+
+// The factor block of one camera from its packed gradient rows (columns 8..10), before the sweep has copied them out.
+__global__ __launch_bounds__(DN_THREADS) void dp_factors_rows_kernel(const int64_t* __restrict__ idx,
+                                                                     const float* __restrict__ grows,
+                                                                     const float* __restrict__ campos, int64_t M, int64_t N,
+                                                                     float* __restrict__ factors, int fill) {
+  const int64_t i = (int64_t)blockIdx.x * DN_THREADS + threadIdx.x;
+  if (fill) {                                       // pass 1 (only when M < N): rows the camera did not see
+    if (i < 3 * N) factors[i] = 0.f;
+    return;
+  }
+  if (i < 3) factors[3 * N + i] = campos[i];
+  if (i >= M) return;
+  const int64_t r = idx ? idx[i] : i;
+  const float4 g = *reinterpret_cast<const float4*>(grows + GSR_ROW_FLOATS * i + 8);
+  factors[3 * r] = g.x; factors[3 * r + 1] = g.y; factors[3 * r + 2] = g.z;
 }
 
 // recv[q][s][f][o]: field f of camera (q + s G) at point lo + o, NaN where that camera did not see the point.
@@ -453,19 +472,33 @@ int gsr_dp_pack_sharded(const int64_t* idx, const float* dL_dcolors, const float
                         float* scale_max, const float* visibility, float* visibility_sum, float* views_sum, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (M < 0 || N < 3 || M > N || (scale_cols != 1 && scale_cols != 2) || num_ranks < 1 || slots_per_rank < 1 || slot < 0 ||
-      slot >= slots_per_rank || !factors_out || !scores_out || !scale_max || !camera_pos)
+      slot >= slots_per_rank || !scores_out || !scale_max || (factors_out && !camera_pos))
     return GSR_ERR_INVALID_ARGUMENT;
   if (visibility && (!visibility_sum || !views_sum)) return GSR_ERR_INVALID_ARGUMENT;
-  if (M > 0 && (!dL_dcolors || !split_score || !prune_cost || !screen_scale)) return GSR_ERR_INVALID_ARGUMENT;
+  if (M > 0 && ((factors_out && !dL_dcolors) || !split_score || !prune_cost || !screen_scale)) return GSR_ERR_INVALID_ARGUMENT;
   const int64_t L = (N + num_ranks - 1) / num_ranks;
   if (M < N) {                                      // rows the camera did not see: zero gradient, NaN scores
-    dp_fill_sharded_kernel<<<dn_grid(3 * N, DN_THREADS), DN_THREADS, 0, stream>>>(factors_out, scores_out, N, L,
+    dp_fill_sharded_kernel<<<dn_grid(factors_out ? 3 * N : N, DN_THREADS), DN_THREADS, 0, stream>>>(factors_out, scores_out, N, L,
                                                                                 slots_per_rank, slot);
     GSR_CHECK_LAUNCH();
   }
   dp_pack_sharded_kernel<<<dn_grid(M > 3 ? M : 3, DN_THREADS), DN_THREADS, 0, stream>>>(
       idx, dL_dcolors, split_score, prune_cost, screen_scale, scale_cols, camera_pos, M, N, L, slots_per_rank, slot,
       factors_out, scores_out, scale_max, visibility, visibility_sum, views_sum);
+  GSR_CHECK_LAUNCH();
+  return GSR_OK;
+}
+
+int gsr_dp_pack_factors_rows(const int64_t* idx, const float* grad_rows, const float* camera_pos, int64_t M, int64_t N,
+                             float* factors_out, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (M < 0 || N < 3 || M > N || !factors_out || !camera_pos || (M > 0 && !grad_rows)) return GSR_ERR_INVALID_ARGUMENT;
+  if (M < N) {
+    dp_factors_rows_kernel<<<dn_grid(3 * N, DN_THREADS), DN_THREADS, 0, stream>>>(nullptr, nullptr, nullptr, M, N, factors_out, 1);
+    GSR_CHECK_LAUNCH();
+  }
+  dp_factors_rows_kernel<<<dn_grid(M > 3 ? M : 3, DN_THREADS), DN_THREADS, 0, stream>>>(M < N ? idx : nullptr, grad_rows, camera_pos,
+                                                                                      M, N, factors_out, 0);
   GSR_CHECK_LAUNCH();
   return GSR_OK;
 }

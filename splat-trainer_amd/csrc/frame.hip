@@ -302,7 +302,17 @@ int64_t gsr_struct_bytes(int32_t which) {
 // The backward half behind one call: K7 -> per-splat reduction -> (inverse map) -> geometry sweep -> SH coefficient
 // gradient, the launches renderer._FrameFn.backward used to make one ctypes call at a time.
 int gsr_frame_backward(const GsrFrameBackwardC* b, void* event_k7_begin, void* event_k7_end, void* stream_) {
+  return gsr_frame_backward_stages(b, 3, event_k7_begin, event_k7_end, stream_);
+}
+
+// stages: bit 0 = K7 + the per-splat reduction (the packed gradient rows are complete behind it), bit 1 = everything
+// after (inverse map, geometry sweep, SH coefficient gradient).  A data-parallel caller runs the two halves as two calls and
+// starts its exchange of the colour-gradient factors -- columns 8..10 of the rows -- in between, so that the transfer runs
+// next to the sweep (distributed.CameraShardedStep: early factor gather).  3 = gsr_frame_backward.
+int gsr_frame_backward_stages(const GsrFrameBackwardC* b, int32_t stages, void* event_k7_begin, void* event_k7_end,
+                              void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (stages < 1 || stages > 3) return GSR_ERR_INVALID_ARGUMENT;
   if (!b || b->N < 0 || b->M < 0 || b->M > b->N || b->O < 0 || b->mode < 0 || b->mode > 2 || b->sh_mode < 0 ||
       b->sh_mode > 2)
     return GSR_ERR_INVALID_ARGUMENT;
@@ -317,7 +327,9 @@ int gsr_frame_backward(const GsrFrameBackwardC* b, void* event_k7_begin, void* e
     if (rc_ < 0) return rc_;          \
   } while (0)
   const bool live = M > 0 && b->O > 0 && b->d_image != nullptr;
-  if (live) {
+  if (!(stages & 1)) {
+    // (the rows were formed by an earlier call)
+  } else if (live) {
     if (!b->partial || !b->vis_partial) return GSR_ERR_INVALID_ARGUMENT;
     if (event_k7_begin && hipEventRecord(reinterpret_cast<hipEvent_t>(event_k7_begin), stream) != hipSuccess)
       return GSR_ERR_LAUNCH_FAILED;
@@ -330,6 +342,7 @@ int gsr_frame_backward(const GsrFrameBackwardC* b, void* event_k7_begin, void* e
     if (hipMemsetAsync(b->grad_rows, 0, (size_t)M * GSR_ROW_FLOATS * sizeof(float), stream) != hipSuccess)
       return GSR_ERR_LAUNCH_FAILED;
   }
+  if (!(stages & 2)) return GSR_OK;
   if (needs_inverse) GSR_TRY(gsr_inverse_map(b->indexes, M, N, b->inverse, stream_));
   if (M > 0 || b->mode == 2)
     GSR_TRY(gsr_project_backward_rows(b->position, b->log_scaling, b->rotation_xyzw, b->alpha_logit, b->indexes, M,

@@ -768,7 +768,7 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 
 extern "C" {
 
-int gsr_abi_version(void) { return 29; }
+int gsr_abi_version(void) { return 30; }
 
 const char* gsr_error_string(int code) {
   switch (code) {

@@ -233,14 +233,15 @@ def dp_pack_sharded(factors: torch.Tensor, scores: torch.Tensor, scale_max: torc
   ``visibility`` + ``sums`` as in dp_pack.  CPU tensors (the gloo tests): the same with torch ops."""
   N, M = int(num_points), int(idx.shape[0])
   G, cpr, _, L = scores.shape
-  if factors.numel() != 3 * N + 3 or L != dp_slice_len(N, G) or scale_max.numel() != N:
+  if (factors is not None and factors.numel() != 3 * N + 3) or L != dp_slice_len(N, G) or scale_max.numel() != N:
     raise ValueError("dp_pack_sharded: buffer shapes do not match (N, ranks)")
   f32 = lambda t: t.detach().to(torch.float32).contiguous()
   scale = f32(screen_scale)
-  if not factors.is_cuda:
-    factors[:3 * N] = 0
-    factors[:3 * N].view(N, 3).index_copy_(0, idx, f32(d_colour))
-    factors[3 * N:] = f32(camera_pos)
+  if not scores.is_cuda:
+    if factors is not None:                 # (None: the block was packed earlier, dp_pack_factors_rows)
+      factors[:3 * N] = 0
+      factors[:3 * N].view(N, 3).index_copy_(0, idx, f32(d_colour))
+      factors[3 * N:] = f32(camera_pos)
     dense = torch.full((2, G * L), float("nan"))
     dense[0, idx], dense[1, idx] = f32(split_score), f32(prune_cost)
     scores[:, slot] = dense.view(2, G, L).permute(1, 0, 2)
@@ -252,10 +253,27 @@ def dp_pack_sharded(factors: torch.Tensor, scores: torch.Tensor, scale_max: torc
     return
   cols = 2 if scale.dim() == 2 else 1
   _lib.check(_lib.load().gsr_dp_pack_sharded(
-      _p(idx.contiguous()) if M < N else None, _p(f32(d_colour)), _p(f32(split_score)), _p(f32(prune_cost)), _p(scale), cols,
-      _p(f32(camera_pos)), M, N, int(G), int(cpr), int(slot), _p(factors), _p(scores), _p(scale_max),
+      _p(idx.contiguous()) if M < N else None, _p(f32(d_colour)) if factors is not None else None, _p(f32(split_score)),
+      _p(f32(prune_cost)), _p(scale), cols, _p(f32(camera_pos)), M, N, int(G), int(cpr), int(slot), _p(factors), _p(scores),
+      _p(scale_max),
       _p(f32(visibility)) if visibility is not None else None, _p(sums[:N]) if visibility is not None else None,
       _p(sums[N:]) if visibility is not None else None, _stream()), "gsr_dp_pack_sharded")
+
+
+def dp_pack_factors_rows(factors: torch.Tensor, num_points: int, idx: torch.Tensor, grad_rows: torch.Tensor,
+                         camera_pos: torch.Tensor):
+  """A camera's (3 N + 3)-float factor block straight from its packed gradient rows (M, 16) -- columns 8..10 are the
+  colour gradient -- i.e. before the backward sweep has copied them out (the early factor gather of the exchange)."""
+  N, M = int(num_points), int(idx.shape[0])
+  if factors.numel() != 3 * N + 3:
+    raise ValueError("dp_pack_factors_rows: factors must hold 3 N + 3 floats")
+  if not factors.is_cuda:
+    factors[:3 * N] = 0
+    factors[:3 * N].view(N, 3).index_copy_(0, idx, grad_rows[:, 8:11].to(torch.float32))
+    factors[3 * N:] = camera_pos.to(torch.float32)
+    return
+  _lib.check(_lib.load().gsr_dp_pack_factors_rows(_p(idx.contiguous()), _p(grad_rows), _p(camera_pos.detach().to(torch.float32).contiguous()),
+                                                  M, N, _p(factors), _stream()), "gsr_dp_pack_factors_rows")
 
 
 def dp_replay_slice(state, recv: torch.Tensor, rank: int, num_cameras: int, num_points: int, slice_out: torch.Tensor,

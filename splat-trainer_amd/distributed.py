@@ -391,7 +391,7 @@ class CameraShardedStep:
   def __init__(self, params: Sequence[torch.Tensor], world_size: int, rank: int, group=None,
                mode: str = DEFAULT_COLLECTIVE, with_stats: bool = True, packed: bool = False,
                exchange_when_single: bool = False, fused_grad_out: bool = True, position_term_local: bool = True,
-               sharded_replay: bool = True):
+               sharded_replay: bool = True, early_gather: bool = True):
     """``packed``: exchange rows padded to the batch's largest visible count instead of the dense per-point block
     (needs a count exchange + host sync per batch).  ``exchange_when_single``: run the exchange even with one rank
     (tests: packing, the collectives on a one-rank group, rebuild and replay on a single GPU).
@@ -403,6 +403,9 @@ class CameraShardedStep:
     rank -- all-to-all of each rank's N / G slice of every camera's scores, in-order replay on the slice, all-gather of the
     2-float state -- and the screen-scale maximum travels as a MAX all-reduce (``_exchange_sharded``); False: the round-3
     form, one dense 6 N + 3 block per camera all-gathered and replayed on every rank (``_exchange_dense``).
+    ``early_gather`` (default, sharded form with ``render_gaussians``' fused node): the colour-factor all-gather is
+    started from inside this rank's last backward pass of the batch, right behind K7 + the per-splat reduction, and runs
+    next to the geometry sweep (``gsr_frame_backward_stages``); False: it is issued with the other collectives.
     ``position_term_local`` (default; factor exchange only): every rank adds the position term of its own cameras'
     colour gradient before the all-reduce -- ``render_gaussians(use_sh=True, sh_collector=...)`` does, from the Jacobian
     its forward pass saves -- and the multi-camera rebuild neither recomputes it for all cameras on every rank nor
@@ -417,6 +420,7 @@ class CameraShardedStep:
     self.world, self.rank, self.group, self.mode, self.with_stats = max(world_size, 1), rank, group, mode, with_stats
     self.packed = packed
     self.sharded = bool(sharded_replay)
+    self.early_gather = bool(early_gather)      # start the factor all-gather from inside the last local backward pass
     self.exchange = self.world > 1 or exchange_when_single
     self.factor = mode == "sh_factor" and self.exchange
     self._slots = {}
@@ -606,6 +610,27 @@ class CameraShardedStep:
     self._send = (torch.empty(cpr, 3 * N + 3, dtype=torch.float32, device=dev),
                   torch.empty(self.world, cpr, 2, L, dtype=torch.float32, device=dev), cpr, L)
     self.scale_max.zero_()
+    # Early factor gather: the fused node's backward pass calls back right behind K7 + the per-splat reduction; the
+    # factor block is packed from the gradient rows there and, once this rank's LAST camera of the batch has been packed,
+    # the all-gather is started -- it then runs next to that camera's geometry sweep instead of behind it.
+    self._early = dict(packed=0, expected=len(shard_cameras(num_cameras, self.rank, self.world)), work=None, blocks=None)
+    self.collector.on_rows = self._early_factors if self.early_gather else None
+
+  def _early_factors(self, indexes, grad_rows, camera_pos):
+    from .densify import dp_pack_factors_rows
+    factors, scores, cpr, L = self._send
+    e = self._early
+    N = self.params[0].shape[0]
+    dp_pack_factors_rows(factors[e["packed"]], N, indexes, grad_rows, camera_pos)
+    e["packed"] += 1
+    if e["packed"] == e["expected"]:
+      for s_ in range(e["expected"], cpr):             # unused slots: an empty camera
+        factors[s_].zero_()
+      if dist.is_available() and dist.is_initialized():
+        e["blocks"] = torch.empty(self.world * cpr, factors.shape[1], dtype=torch.float32, device=factors.device)
+        e["work"] = dist.all_gather_into_tensor(e["blocks"], factors, group=self.group, async_op=True)
+      else:
+        e["blocks"] = factors
 
   def _sharded_pack(self, slot: int, points):
     """Camera ``slot`` of this rank into the send buffers (``points`` None: an empty camera), right behind its backward
@@ -615,12 +640,14 @@ class CameraShardedStep:
     N, dev = self.params[0].shape[0], self.params[0].device
     if points is None:
       e_i, e_f = torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float32, device=dev)
-      dp_pack_sharded(factors[slot], scores, self.scale_max, N, slot, e_i, e_f.view(0, 3), e_f, e_f, e_f.view(0, 2),
-                      torch.zeros(3, dtype=torch.float32, device=dev))
+      early = self._early["blocks"] is not None          # (the gather has left: its unused slots were zero-filled there)
+      dp_pack_sharded(None if early else factors[slot], scores, self.scale_max, N, slot, e_i, e_f.view(0, 3), e_f, e_f,
+                      e_f.view(0, 2), torch.zeros(3, dtype=torch.float32, device=dev))
       return
     idx, d_colour, cam = self.collector.items[slot][:3]
-    dp_pack_sharded(factors[slot], scores, self.scale_max, N, slot, idx, d_colour, points.split_score, points.prune_cost,
-                    points.screen_scale, cam, visibility=points.visibility, sums=self.bucket.extra)
+    early = self._early["packed"] > slot               # this camera's factor block was packed from its gradient rows already
+    dp_pack_sharded(None if early else factors[slot], scores, self.scale_max, N, slot, idx, d_colour, points.split_score,
+                    points.prune_cost, points.screen_scale, cam, visibility=points.visibility, sums=self.bucket.extra)
 
   def _exchange_sharded(self, num_cameras: int, local: List[dict], point_state):
     """The default exchange since round 4.  Per batch, G ranks, ``cpr`` camera slots per rank, L = ceil(N / G):
@@ -650,13 +677,22 @@ class CameraShardedStep:
     # (the packs above also added this rank's cameras to the two sum columns the gradient all-reduce carries)
     pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True, even_single=True) if live else None
     pending_max = dist.all_reduce(self.scale_max, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if live else None
-    if live:
+    early = self._early
+    self.collector.on_rows = None
+    if early["blocks"] is not None:                    # the factor gather left from inside the last backward pass
+      blocks = early["blocks"]
+      if early["work"] is not None:
+        early["work"].wait()
+    elif live:
       blocks = torch.empty(G * cpr, 3 * N + 3, dtype=torch.float32, device=dev)
       dist.all_gather_into_tensor(blocks, factors, group=self.group)
+    else:
+      blocks = factors
+    if live:
       recv = torch.empty_like(scores)
       dist.all_to_all_single(recv, scores, group=self.group)
     else:
-      blocks, recv = factors, scores
+      recv = scores
     mine = torch.empty(2, L, dtype=torch.float32, device=dev)
     dp_replay_slice(point_state, recv, self.rank, num_cameras, N, mine)
     if live:

@@ -780,7 +780,15 @@ class _FrameFn(torch.autograd.Function):
           _ptr(st.final_T), _ptr(st.last), _ptr(st.image), _ptr(ctx.jac), seg, _ptr(dimg), _ptr(dg), _ptr(dd),
           _ptr(partial), _ptr(grows), _ptr(inv), _ptr(dcol), _ptr(d_pos), _ptr(d_ls), _ptr(d_rot), _ptr(d_al), mode,
           _ptr(d_sh), sh_mode, _ptr(st.prune_cost), _ptr(st.split_score), _ptr(_vis_out(st, live)))
-      _lib.check(lib.gsr_frame_backward(C.byref(args), ev[0], ev[1], _stream()), "gsr_frame_backward")
+      early = getattr(collector, "on_rows", None) if collector is not None else None
+      if early is not None and M > 0:
+        # data-parallel: K7 + reduction first; the caller packs the colour-gradient factors straight from the packed rows
+        # and starts their all-gather, which then runs next to the sweep enqueued below
+        _lib.check(lib.gsr_frame_backward_stages(C.byref(args), 1, ev[0], ev[1], _stream()), "gsr_frame_backward_stages(1)")
+        early(indexes, grows, cam)
+        _lib.check(lib.gsr_frame_backward_stages(C.byref(args), 2, None, None, _stream()), "gsr_frame_backward_stages(2)")
+      else:
+        _lib.check(lib.gsr_frame_backward(C.byref(args), ev[0], ev[1], _stream()), "gsr_frame_backward")
     else:
       dcol = torch.zeros(0, 3, dtype=torch.float32, device=dev) if want_sh else None
     if collector is not None:              # data-parallel factor exchange: keep only the colour gradient

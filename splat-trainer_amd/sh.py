@@ -35,6 +35,10 @@ class ShFactorCollector:
     # alone and never reads the coefficient rows; False = the rebuild recomputes the term for all cameras on every rank
     # (what the three-call form needs: evaluate_sh_at hands on colour gradients only).
     self.position_term_local = False
+    # Optional hook (distributed.CameraShardedStep): called by the fused node's backward pass as on_rows(indexes (M,),
+    # grad_rows (M,16), camera_pos) right behind K7 + the per-splat reduction, BEFORE the geometry sweep is enqueued --
+    # the colour-gradient factors are columns 8..10 of the rows, so their exchange can start there.
+    self.on_rows = None
 
   def clear(self):
     self.items.clear()

@@ -180,3 +180,18 @@ def test_sharded_pack_replay_finish_match_their_cpu_forms():
   for f in ("split_score", "prune_cost", "visibility"):
     assert torch.allclose(getattr(a[4], f), getattr(b[4], f).cpu(), rtol=2e-5, atol=2e-6), f        # expf/logf: host libm vs device
   assert (a[4].split_score != torch.linspace(-1, 1, n)).all()               # every point was replayed (camera `full`)
+
+
+def test_early_factor_gather_changes_nothing(one_rank_group):
+  """The colour-factor all-gather started from inside the last backward pass of the batch (factor blocks packed from the
+  gradient rows right behind K7 + the per-splat reduction, gsr_frame_backward_stages) against the same exchange issued
+  after the backward pass: every gradient and the whole controller state bit-identical -- with the frustum cull active,
+  and with three cameras on one rank (the gather leaves with the third)."""
+  g, cams = _scene(True)
+  a = _run(g, cams, exchange_when_single=True, early_gather=True)
+  b = _run(g, cams, exchange_when_single=True, early_gather=False)
+  for k in a[0]:
+    assert torch.equal(a[0][k], b[0][k]), k
+  for f in ("prune_cost", "split_score", "max_scale_px", "points_in_view", "visibility"):
+    assert torch.equal(getattr(a[1], f), getattr(b[1], f)), f
+  assert torch.equal(a[2], b[2])

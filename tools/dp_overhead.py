@@ -76,7 +76,7 @@ def render_backward(j, cam, grad_out, collector):
 
 
 for world in (1, WORLD):
-  dp = CameraShardedStep(params, world, 0)
+  dp = CameraShardedStep(params, world, 0, early_gather=__import__('os').environ.get('DP_EARLY', '1') == '1')
   state = PointState.new_zeros(N, dev)
   for _ in range(30):
     dp.run(batch[:world] if world == 1 else batch, render_backward, point_state=state)

@@ -15,7 +15,8 @@ work is fixed as N grows (weak scaling).  value = Gaussians x cameras / second o
 resident in HBM when the timed region starts.
 
 Workloads (SURVEY.md §8d):  c2 = Scene A, 500k Gaussians, 1920x1080, SH deg 3 (default, BASELINE configs[1]);
-c3 = Scene B, 3M Gaussians, 1080p, SH 3, 8 orbit cameras;  c1 = Scene A 10k / 256^2 / SH0.
+c3 = Scene B, 3M Gaussians, 1080p, SH 3, 8 orbit cameras (the default at --gpus > 1);  c1 = Scene A 10k / 256^2 / SH0;
+c5 = Scene B 10M / 4K;  c5culled = the same from an orbit of radius 1.2 (a third of the points survive the frustum cull).
 """
 from __future__ import annotations
 
@@ -46,6 +47,8 @@ WORKLOADS = {
     "c2": dict(scene="A", n=500_000, w=1920, h=1080, sh=3),
     "c3": dict(scene="B", n=3_000_000, w=1920, h=1080, sh=3),
     "c5": dict(scene="B", n=10_000_000, w=3840, h=2160, sh=3),
+    # c5's culled variant: orbit radius 1.2 around the unit ball, the frustum cull removes ~2/3
+    "c5culled": dict(scene="B", n=10_000_000, w=3840, h=2160, sh=3, radius=1.2),
 }
 
 
@@ -66,7 +69,8 @@ def make_workload(name: str, world: int):
     cams = [sta.CameraParams(yaw(cam.T_camera_world, 1.5 * k), cam.projection, cam.image_size, cam.near_plane,
                              cam.far_plane) for k in range(max(world, 1))]
   else:
-    g, cams = synthetic.scene_b(w["n"], w["w"], w["h"], sh_degree=w["sh"], seed=1, num_cameras=max(world, 8))
+    g, cams = synthetic.scene_b(w["n"], w["w"], w["h"], sh_degree=w["sh"], seed=1, num_cameras=max(world, 8),
+                                radius=w.get("radius", 3.0))
   return g, cams, w
 
 

@@ -494,10 +494,11 @@ def main():
                                + (", three-call form" if args.form == "three_call" else ""),
                    "gaussians": N, "visible": M, "tile_overlaps": O, "pixels": P, "cameras_per_step": cameras_per_step,
                    "parallelism": ("dp1 (one GPU: gradients accumulate in place, no collective)" if world == 1 else
-                                   f"dp{world} (camera-sharded; two collectives per step, no host sync: all_reduce of "
-                                   f"{bucket.flat.numel() * 4 / 1e6:.0f} MB geometry grads + sums, all_gather of {world} x "
-                                   f"{(6 * N + 3) * 4 / 1e6:.0f} MB per-camera blocks = colour-gradient factors + controller "
-                                   f"scores)" if factor_mode else
+                                   f"dp{world} (camera-sharded, sharded exchange, no host sync: SUM all_reduce of "
+                                   f"{bucket.flat.numel() * 4 / 1e6:.0f} MB geometry grads + sums, MAX all_reduce of {N * 4 / 1e6:.0f} MB "
+                                   f"screen scale, all_gather of {world} x {(3 * N + 3) * 4 / 1e6:.0f} MB colour-gradient factor blocks "
+                                   f"(started inside the backward pass), all_to_all + all_gather of the controller scores by "
+                                   f"point slices, {2 * 2 * ((N + world - 1) // world) * 4 / 1e6:.1f} MB per peer)" if factor_mode else
                                    f"dp{world} (camera-sharded, fused {args.collective} of {bucket.flat.numel() * 4 / 1e6:.0f} MB grads)"),
                    "parity": "parity unpinned by the reference (its rasterizer is an absent third-party package); "
                              "HIP vs this build's fp64 oracle is asserted by tests/ (-m gpu), observed errors in "

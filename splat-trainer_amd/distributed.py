@@ -675,19 +675,22 @@ class CameraShardedStep:
       self._sharded_pack(s, None)
     self._send = None
     # (the packs above also added this rank's cameras to the two sum columns the gradient all-reduce carries)
-    pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True, even_single=True) if live else None
-    pending_max = dist.all_reduce(self.scale_max, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if live else None
+    # ORDER OF ISSUE -- the same on every rank, whatever happened during its backward passes: the factor gather FIRST (a
+    # rank whose last camera went through the fused node issued it from inside that backward pass; every other rank --
+    # no camera in this batch, a callback in the three-call form, early_gather off -- issues it here, before anything
+    # else), then SUM all-reduce, MAX all-reduce, score all-to-all, state gather.
     early = self._early
     self.collector.on_rows = None
-    if early["blocks"] is not None:                    # the factor gather left from inside the last backward pass
-      blocks = early["blocks"]
-      if early["work"] is not None:
-        early["work"].wait()
+    work_gather = None
+    if early["blocks"] is not None:                    # left from inside the last backward pass
+      blocks, work_gather = early["blocks"], early["work"]
     elif live:
       blocks = torch.empty(G * cpr, 3 * N + 3, dtype=torch.float32, device=dev)
-      dist.all_gather_into_tensor(blocks, factors, group=self.group)
+      work_gather = dist.all_gather_into_tensor(blocks, factors, group=self.group, async_op=True)
     else:
       blocks = factors
+    pending = self.bucket.all_reduce(group=self.group, mode="all_reduce", async_op=True, even_single=True) if live else None
+    pending_max = dist.all_reduce(self.scale_max, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if live else None
     if live:
       recv = torch.empty_like(scores)
       dist.all_to_all_single(recv, scores, group=self.group)
@@ -700,6 +703,8 @@ class CameraShardedStep:
       dist.all_gather_into_tensor(gathered.view(G * 2, L), mine, group=self.group)
     else:
       gathered = mine.view(1, 2, L)
+    if work_gather is not None:
+      work_gather.wait()
     if pending is not None:
       pending.wait()                                   # d_pos below adds to the all-reduced position gradient
     if pending_max is not None:

@@ -210,6 +210,10 @@ def _stats_worker(rank, world, port, out_path, num_cameras):
         t.zero_()
       grad_out.geometry_uninitialized = False
     grad_out.position[d["idx"]] += float(j + 1)
+    if collector.on_rows is not None:                   # what the fused node's backward pass does between its two halves:
+      rows = torch.zeros(d["idx"].shape[0], 16)         # the packed gradient rows carry the colour gradient in columns 8..10
+      rows[:, 8:11] = d["dcol"]
+      collector.on_rows(d["idx"], rows, d["cam"])       # -> factor block packed, and (last local camera) the gather started
     collector.items.append((d["idx"], d["dcol"], d["cam"]))
     pts = sta.RenderedPoints(idx=d["idx"], depths=torch.zeros(d["idx"].shape[0], 1), opacity=torch.zeros(d["idx"].shape[0]),
                              screen_scale=torch.stack([d["screen_scale_max"], 0.5 * d["screen_scale_max"]], dim=1),

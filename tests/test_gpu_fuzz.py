@@ -92,3 +92,29 @@ def test_flips_are_rare():
   flips = [s for s in seen if FLIPPED[s]]
   print("fuzz seeds with an isolated flip:", flips, "sensitive:", [s for s in SENSITIVE if FLIPPED.get(s)])
   assert len(flips) <= len(seen) // 8, flips
+
+
+@pytest.mark.parametrize("seed", [300, 301, 302, 303, 304, 305])
+def test_random_scene_with_many_large_splats(seed):
+  """The sweep's scenes with a tenth of their splats blown up 8-40x (supports of tens to hundreds of tiles, hanging over
+  every image border, on images whose sides are no multiple of 16): the wave-cooperative count / emit of large extents and
+  the group-wise reduction of large slot ranges (csrc/binning.hip) against the oracle, under the same rules as above."""
+  g, cam, cfg = random_case(seed)
+  gen = torch.Generator().manual_seed(seed)
+  n = g.position.shape[0]
+  pick = torch.randperm(n, generator=gen)[: max(2, n // 10)]
+  ls, al = g.log_scaling.clone(), g.alpha_logit.clone()
+  ls[pick] += 2.1 + 1.6 * torch.rand(pick.numel(), 1, generator=gen)
+  al[pick] = -2.5 + 1.5 * torch.rand(pick.numel(), 1, generator=gen)      # faint: what lies behind them still counts
+  g = sta.Gaussians3D(g.position, g.rotation, ls, al, g.feature)
+  hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+  orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+  assert len(set(hip["idx"].tolist()) ^ set(orc["idx"].tolist())) == 0
+  live = []
+  for k in KEYS:
+    if orc[k].abs().max() == 0:
+      assert hip[k].abs().max() == 0, (seed, k)
+      continue
+    live.append(k)
+    clean_or_isolated_flip(f"fuzz large {seed}", k, hip[k], orc[k], 2e-4)
+  compare_explained(f"fuzz large {seed} (explained)", hip, orc, 2e-4, keys=live)

@@ -35,14 +35,14 @@ def _hipcc() -> str:
   return exe
 
 
-def build_hip(force: bool = False, verbose: bool = False, out: str = LIB_PATH, defines=()) -> str:
-  """``out`` / ``defines``: experimental variants (``-DNAME[=v]``) built next to the product library."""
+def build_hip(force: bool = False, verbose: bool = False, out: str = LIB_PATH, defines=(), flags=()) -> str:
+  """``out`` / ``defines`` / ``flags``: experimental variants (``-DNAME[=v]``, raw compiler flags) built next to the product library."""
   srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
   deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
   if not force and _newer(out, deps):
     return out
   cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-         "-Wno-unused-value", "-o", out] + [f"-D{d}" for d in defines] + srcs
+         "-Wno-unused-value", "-o", out] + [f"-D{d}" for d in defines] + list(flags) + srcs
   if verbose:
     print(" ".join(cmd), flush=True)
   subprocess.run(cmd, check=True, cwd=CSRC)

@@ -18,7 +18,8 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libgsplat_hip.so")
 HOSTMATH_PATH = os.path.join(PKG_DIR, "libgsr_hostmath.so")
 HIP_SOURCES = ["prims.hip", "geometry.hip", "binning.hip", "composite.hip", "frame.hip", "ssim.hip", "optim.hip", "densify.hip"]
-HEADERS = ["gsr_math.h", "gsr_device.h", "gsr_dpp_reduce.h", os.path.join("..", "..", "include", "gsplat_hip.h")]
+HEADERS = ["gsr_math.h", "gsr_device.h", "gsr_dpp_reduce.h", "composite_k7_windows.inc", "composite_k7_xflex.inc",
+           os.path.join("..", "..", "include", "gsplat_hip.h")]
 
 
 def _newer(target: str, sources) -> bool:

@@ -791,48 +791,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
         if (!(s.halves & (1u << h))) continue;                            // scalar test: support misses this half
         const float dy = (h ? fy0 + 8.f : fy0) - s.v;
 #if GSR_K7_XFLEX
-        if (narrow) {
-#pragma clang fp contract(off)
-          const float T = sel ? T2[h].y : T2[h].x, gaf = sel ? ga2[h].y : ga2[h].x;
-          const float g0 = sel ? g2[h][0].y : g2[h][0].x, g1 = sel ? g2[h][1].y : g2[h][1].x, g2f = sel ? g2[h][2].y : g2[h][2].x;
-          const int lastv = sel ? lastc[2 * h + 1] : lastc[2 * h];
-          // q, t = conic d exactly as eval_q2 / eval_qt form them, for one pixel
-          const float bdy = s.B * dy, cdy = s.C * dy;
-          const float txf = __builtin_fmaf(dxs, s.A, bdy), tyf = __builtin_fmaf(dxs, s.B, cdy);
-          const float qf = __builtin_fmaf(dxs * s.A, dxs, __builtin_fmaf((s.B + s.B) * dy, dxs, cdy * dy));
-          const bool hit = pos < lastv && qf <= s.qlim;
-          if (__ballot(hit) != 0ull) {
-            const float a_raw = __builtin_amdgcn_exp2f(__builtin_fmaf(qf, -0.72134752044448170368f, s.l2op));
-            float alpha = __builtin_amdgcn_fmed3f(a_raw, 0.f, rp.clamp_max_alpha);
-            alpha = hit ? alpha : 0.f;
-            const float inv = __builtin_amdgcn_rcpf(1.f - alpha);          // rcp(1) == 1 exactly
-            const float Tb = T * inv;
-            const float w = alpha * Tb;
-            float gc = g0 * s.f0;
-            if (C > 1) gc = __builtin_fmaf(g1, s.f1, gc);
-            if (C > 2) gc = __builtin_fmaf(g2f, s.f2, gc);
-            df2[0].x = __builtin_fmaf(w, g0, df2[0].x);
-            if (C > 1) df2[1].x = __builtin_fmaf(w, g1, df2[1].x);
-            if (C > 2) df2[2].x = __builtin_fmaf(w, g2f, df2[2].x);
-            const float dLda = Tb * gc - gaf * inv;
-            const float gan = __builtin_fmaf(gc, w, gaf);
-            T2[h] = sel ? (v2f){T2[h].x, Tb} : (v2f){Tb, T2[h].y};
-            ga2[h] = sel ? (v2f){ga2[h].x, gan} : (v2f){gan, ga2[h].y};
-            prune2.x = __builtin_fmaf(__builtin_fabsf(dLda), alpha, prune2.x);
-            float GdG = a_raw * dLda;
-            GdG = (hit && a_raw <= rp.clamp_max_alpha) ? GdG : 0.f;
-            dop2.x += GdG;
-            const float px_ = GdG * dxs, py_ = GdG * dy;
-            mx2.x += px_;
-            my2.x += py_;
-            mxx2.x = __builtin_fmaf(px_, dxs, mxx2.x);
-            mxy2.x = __builtin_fmaf(px_, dy, mxy2.x);
-            myy2.x = __builtin_fmaf(py_, dy, myy2.x);
-            const float nn = __builtin_fmaf(tyf, tyf, txf * txf);
-            split2.x = __builtin_fmaf(__builtin_fabsf(GdG), __builtin_amdgcn_sqrtf(nn), split2.x);
-          }
-          continue;
-        }
+#include "composite_k7_xflex.inc"
 #endif
         v2f q, tx_, ty_;
         eval_qt(dx2, dy, s.A, s.B, s.C, q, tx_, ty_);
@@ -930,267 +889,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7_WAVES
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// K7 with flexible 64-pixel windows (GSR_K7_WINDOWS; VERDICT r3 item 1a: "pixel state in LDS").
-// The kernel above evaluates a pair on whole tile halves (8 x 16 pixels, two per lane, packed): 180 evaluated pixels per
-// pair of which 41 contribute on c2.  Here the pixel state of the tile -- (T, g . colour behind) and the constants
-// (dL/dC, last contributor) -- lives in LDS instead of registers, so the lane <-> pixel map is free: a pair is evaluated on
-// 64-pixel windows (8 x 8, 16 x 4 or 4 x 16, one pixel per lane, plain fp32) laid over the intersection of the splat's
-// pixel bounding box (row words 12 / 13) with the tile.  Same list walk, same skip flags, same per-pair reduction
-// through LDS (without the eleven folds of packed halves), same contribute / skip decisions as the forward walk (q from
-// the same single-rounded offsets through the same fma chain).  Sums differ from the packed kernel's by association
-// order only.
+// K7 with flexible 64-pixel windows and the tile's pixel state in LDS: measured and rejected, lives in
+// composite_k7_windows.inc and is compiled only for the variant build that reproduces the numbers on file.
 #ifndef GSR_K7_WINDOWS
 #define GSR_K7_WINDOWS 0
 #endif
-#ifndef GSR_K7W_WAVES
-#define GSR_K7W_WAVES 4
+#if GSR_K7_WINDOWS
+#include "composite_k7_windows.inc"
 #endif
-#define GSR_K7W_PIX 308            // 16 x 16 pixels + the rows a window may hang over the tile's lower edge (never hit)
-#define GSR_K7W_RED 68             // words per value row of the reduction block (64 lanes + 4: conflict-free 16-byte reads)
-
-struct SplatW {
-  float u, v, A, B, C, qlim, f0, f1, f2, l2op;
-  uint32_t bx, by;
-};
-template <int C>
-__device__ __forceinline__ SplatW load_splat_win(const float* __restrict__ rec, uint32_t packed) {
-  const uint32_t k = packed & 0x3FFFFFFFu;
-  const float4* r = reinterpret_cast<const float4*>(rec + (size_t)GSR_ROW_FLOATS * k);
-  const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-  const float2 r3 = *reinterpret_cast<const float2*>(rec + (size_t)GSR_ROW_FLOATS * k + 12);
-  SplatW s;
-  s.u = r0.x; s.v = r0.y; s.A = r0.z; s.B = r0.w; s.C = r1.x; s.qlim = r1.z; s.f0 = r1.w;
-  s.f1 = r2.x; s.f2 = r2.y; s.l2op = r2.w;
-  s.bx = __float_as_uint(r3.x); s.by = __float_as_uint(r3.y);
-  return s;
-}
-
-struct WinAcc {             // the eleven per-pair sums of one lane
-  float mx, my, mxx, mxy, myy, dop, prune, split, df0, df1, df2;
-};
-
-// One 64-pixel window of one pair: lane -> pixel (ax + lx, ay + ly), state through LDS.  All of (ax, ay, pos, s) are
-// wave-uniform.  fxl / fyl: centre of the lane's pixel for anchor (0, 0), exact.
-template <int C>
-__device__ __forceinline__ void win_step(const SplatW& s, int pos, int a_pix, float axf, float ayf, int lp, float fxl,
-                                         float fyl, float2* __restrict__ s_st, const float4* __restrict__ s_cg,
-                                         float cmax, WinAcc& acc, int skip_cols = 0) {
-#pragma clang fp contract(off)
-  const int p = lp + a_pix;
-  const float dx = (fxl + axf) - s.u;                      // centre exact (small integers + 0.5), then ONE rounding
-  const float dy = (fyl + ayf) - s.v;
-  const float4 cg = s_cg[p];
-  // q, t = conic d exactly as eval_q2 / eval_qt form them (one pixel instead of two)
-  const float bdy = s.B * dy, cdy = s.C * dy;
-  const float tx_ = __builtin_fmaf(dx, s.A, bdy), ty_ = __builtin_fmaf(dx, s.B, cdy);
-  const float t = (s.B + s.B) * dy, uu = cdy * dy;
-  const float q = __builtin_fmaf(dx * s.A, dx, __builtin_fmaf(t, dx, uu));
-  // (skip_cols: leading columns of a strip whose anchor was pulled back into the tile -- an earlier strip had them)
-  const bool hit = pos < __float_as_int(cg.w) && q <= s.qlim && (lp & 3) >= skip_cols;
-  if (__ballot(hit) == 0ull) return;
-  const float2 st = s_st[p];
-  const float a_raw = __builtin_amdgcn_exp2f(__builtin_fmaf(q, -0.72134752044448170368f, s.l2op));
-  float alpha = __builtin_amdgcn_fmed3f(a_raw, 0.f, cmax);
-  alpha = hit ? alpha : 0.f;
-  const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-  const float Tb = st.x * inv;
-  const float w = alpha * Tb;
-  float gc = cg.x * s.f0;
-  if (C > 1) gc = __builtin_fmaf(cg.y, s.f1, gc);
-  if (C > 2) gc = __builtin_fmaf(cg.z, s.f2, gc);
-  acc.df0 = __builtin_fmaf(w, cg.x, acc.df0);
-  if (C > 1) acc.df1 = __builtin_fmaf(w, cg.y, acc.df1);
-  if (C > 2) acc.df2 = __builtin_fmaf(w, cg.z, acc.df2);
-  const float dLda = Tb * gc - st.y * inv;
-  const float ga = __builtin_fmaf(gc, w, st.y);
-  if (hit) s_st[p] = make_float2(Tb, ga);                 // (lanes that did not contribute leave their pixel alone)
-  acc.prune = __builtin_fmaf(__builtin_fabsf(dLda), alpha, acc.prune);
-  float GdG = a_raw * dLda;
-  GdG = (hit && a_raw <= cmax) ? GdG : 0.f;
-  acc.dop += GdG;
-  const float px_ = GdG * dx, py_ = GdG * dy;
-  acc.mx += px_;
-  acc.my += py_;
-  acc.mxx = __builtin_fmaf(px_, dx, acc.mxx);
-  acc.mxy = __builtin_fmaf(px_, dy, acc.mxy);
-  acc.myy = __builtin_fmaf(py_, dy, acc.myy);
-  const float nn = __builtin_fmaf(ty_, ty_, tx_ * tx_);
-  acc.split = __builtin_fmaf(__builtin_fabsf(GdG), __builtin_amdgcn_sqrtf(nn), acc.split);
-}
-
-template <int C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_K7W_WAVES, GSR_K7W_WAVES))) void composite_bwd_win_kernel(
-    const float* __restrict__ rec, const uint32_t* __restrict__ sorted_rank, const uint32_t* __restrict__ sorted_inst,
-    const float* __restrict__ pair_vis, const uint32_t* __restrict__ tile_range, int W, int H, int tiles_x, int num_tiles,
-    GsrRasterParams rp, const float* __restrict__ final_T, const int* __restrict__ last,
-    const float* __restrict__ dL_dimage, const float* __restrict__ image, float* __restrict__ partial, SegDev seg,
-    uint32_t seg_capacity, uint32_t seg_blocks) {
-  // block -> work unit: exactly composite_bwd_kernel's (segments first, then whole tiles longest class first)
-  int tile, lo = 0, seg_hi = 0x7fffffff;
-  uint32_t sidx = 0u;
-  const bool is_seg = blockIdx.x < seg_blocks;
-  if (is_seg) {
-    sidx = gsr_xcd_group_remap(blockIdx.x, GSR_K7_SEG_GROUP_LOG2);
-    if (sidx >= min(seg.seg_total[0], seg_capacity)) return;
-    const uint32_t* d = seg.seg_desc + 4 * (size_t)sidx;
-    tile = (int)d[0];
-    const uint32_t tstart = tile_range[2 * tile];
-    lo = (int)(d[1] - tstart);
-    seg_hi = (int)(d[2] - tstart);
-  } else {
-    const uint32_t b = blockIdx.x - seg_blocks;
-    if (seg.tile_order) {
-      tile = ordered_tile(seg, num_tiles, b, (int)threadIdx.x);
-      if (tile < 0) return;
-    } else {
-      if ((int)b >= num_tiles) return;
-      tile = gsr_xcd_remap((int)b, num_tiles);
-    }
-    if (seg.tile_seg && seg.tile_seg[2 * tile + 1] != 0u) return;
-  }
-  const int lane = (int)threadIdx.x;
-  const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int tile_px0 = tx * 16, tile_py0 = ty * 16;
-  const uint32_t start = tile_range[2 * tile];
-
-  __shared__ float2 s_st[GSR_K7W_PIX];
-  __shared__ float4 s_cg[GSR_K7W_PIX];
-  __shared__ float red[11 * GSR_K7W_RED];
-  if (lane < GSR_K7W_PIX - 256) {                          // rows under the tile: last = 0, nothing ever contributes
-    s_st[256 + lane] = make_float2(1.f, 0.f);
-    s_cg[256 + lane] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-  }
-  int tile_last = 0;
-#pragma unroll
-  for (int pp = 0; pp < 4; ++pp) {
-    const int lx = (lane & 7) + 8 * (pp & 1), ly = (lane >> 3) + 8 * (pp >> 1);
-    const int px = tile_px0 + lx, py = tile_py0 + ly;
-    float t = 1.f, gb = 0.f, g[3] = {0.f, 0.f, 0.f};
-    int lastv = 0;
-    if (px < W && py < H) {
-      const size_t pix = (size_t)py * W + px;
-      t = final_T[pix];
-      float4 tc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (is_seg) {
-        tc = seg.seg_TC[256 * (size_t)sidx + 64 * pp + lane];
-        t = tc.x < 0.f ? 1.f : tc.x;
-      }
-      const float upto[3] = {tc.y, tc.z, tc.w};
-      lastv = last[pix];
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        g[c] = dL_dimage[pix * C + c];
-        if (is_seg) gb = fmaf(g[c], image[pix * C + c] - upto[c], gb);
-      }
-    }
-    s_st[ly * 16 + lx] = make_float2(t, gb);
-    s_cg[ly * 16 + lx] = make_float4(g[0], g[1], g[2], __int_as_float(lastv));
-    tile_last = max(tile_last, lastv);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tile_last = max(tile_last, __shfl_xor(tile_last, o, 64));
-  tile_last = __builtin_amdgcn_readfirstlane(tile_last);
-  const int hi = min(tile_last, seg_hi);
-  if (hi <= lo) return;
-  gsr_wave_lds_fence();
-
-  // lane -> pixel inside a window of each shape (pixel index at anchor 0 and exact centre coordinates at anchor 0)
-  const int lp8 = (lane >> 3) * 16 + (lane & 7), lp16 = (lane >> 4) * 16 + (lane & 15), lp4 = (lane >> 2) * 16 + (lane & 3);
-  const float bx0 = (float)tile_px0 + 0.5f, by0 = (float)tile_py0 + 0.5f;
-  const float fx8 = bx0 + (float)(lane & 7), fy8 = by0 + (float)(lane >> 3);
-  const float fx16 = bx0 + (float)(lane & 15), fy16 = by0 + (float)(lane >> 4);
-  const float fx4 = bx0 + (float)(lane & 3), fy4 = by0 + (float)(lane >> 2);
-  const int rslot = lane < 44 ? (lane >> 2) * GSR_K7W_RED + (lane & 3) * 16 : 0;   // reader 4k+p: quarter p of value k
-  const uint32_t red_base = (uint32_t)(uintptr_t)red;
-
-  for (int cbase = lo + (((hi - lo - 1) >> 6) << 6); cbase >= lo; cbase -= 64) {
-    const int n = min(64, hi - cbase);
-    const uint32_t li = start + (uint32_t)cbase + (uint32_t)lane;
-    const float pv = (lane < n) ? pair_vis[li] : 0.f;
-    const int my_rank = (lane < n) ? (int)sorted_rank[li] : 0;
-    const int my_inst = (lane < n) ? (int)sorted_inst[li] : 0;
-    uint64_t flags = __ballot(pv > 0.f);
-    if (flags == 0ull) continue;
-    int j = 63 - __builtin_clzll(flags);
-    SplatW nxt = load_splat_win<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
-    uint32_t inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
-    while (true) {
-      const SplatW s = nxt;
-      const uint32_t inst_j = inst_nxt;
-      const int pos = cbase + j;
-      flags &= ~(1ull << j);
-      const bool more = flags != 0ull;
-      if (more) {
-        j = 63 - __builtin_clzll(flags);
-        nxt = load_splat_win<C>(rec, (uint32_t)__builtin_amdgcn_readlane(my_rank, j));
-        inst_nxt = (uint32_t)__builtin_amdgcn_readlane(my_inst, j);
-      }
-      // the splat's pixel box cut to the tile (wave-uniform integer arithmetic)
-      const int x0 = max((int)(int16_t)(s.bx & 0xFFFFu) - tile_px0, 0), x1 = min(((int)s.bx >> 16) - tile_px0, 15);
-      const int y0 = max((int)(int16_t)(s.by & 0xFFFFu) - tile_py0, 0), y1 = min(((int)s.by >> 16) - tile_py0, 15);
-      const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-      WinAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (w > 0 && h > 0) {
-        const int n88x = w <= 8 ? 1 : 2, n88y = h <= 8 ? 1 : 2, n88 = n88x * n88y;
-        const int n164 = (h + 3) >> 2, n416 = (w + 3) >> 2;
-        if ((w <= 8 && h <= 8) || (h > 4 && w > 4 && n88 <= n164 && n88 <= n416)) {
-          // 8 x 8 windows: one where the box fits (anchored at the box, kept inside the tile), else the quadrants it reaches
-          const int ax0 = n88x == 1 ? min(x0, 8) : 0, ay0 = n88y == 1 ? min(y0, 8) : 0;
-          for (int wy = 0; wy < n88y; ++wy)
-            for (int wx = 0; wx < n88x; ++wx) {
-              const int ax = ax0 + 8 * wx, ay = ay0 + 8 * wy;
-              win_step<C>(s, pos, ay * 16 + ax, (float)ax, (float)ay, lp8, fx8, fy8, s_st, s_cg, rp.clamp_max_alpha, acc);
-            }
-        } else if (h <= 4 || (w > 4 && n164 <= n416)) {
-          // 16 x 4 strips from the box's first row down (a strip may hang over the tile's lower edge: rows that hold no pixel)
-          for (int k = 0; k < n164; ++k) {
-            const int ay = (h <= 4) ? min(y0, 12) : y0 + 4 * k;
-            win_step<C>(s, pos, ay * 16, 0.f, (float)ay, lp16, fx16, fy16, s_st, s_cg, rp.clamp_max_alpha, acc);
-          }
-        } else {
-          // 4 x 16 strips from the box's first column on (columns right of the tile lie outside the box: q > qlim there)
-          for (int k = 0; k < n416; ++k) {
-            const int ax = min(x0 + 4 * k, 12);           // (kept inside the tile: a column right of it would alias the next row)
-            win_step<C>(s, pos, ax, (float)ax, 0.f, lp4, fx4, fy4, s_st, s_cg, rp.clamp_max_alpha, acc, x0 + 4 * k - ax);
-          }
-        }
-      }
-      // per-pair reduction through LDS: value rows of 64 lanes (+4 words), parked by lane id without an address register
-      {
-        asm volatile("s_mov_b32 m0, %11\n"
-                     "s_nop 0\n"                                  /* hazard: SALU write of M0 -> LDS add-TID needs a wait state */
-                     "ds_write_addtid_b32 %0 offset:0\n"
-                     "ds_write_addtid_b32 %1 offset:272\n"
-                     "ds_write_addtid_b32 %2 offset:544\n"
-                     "ds_write_addtid_b32 %3 offset:816\n"
-                     "ds_write_addtid_b32 %4 offset:1088\n"
-                     "ds_write_addtid_b32 %5 offset:1360\n"
-                     "ds_write_addtid_b32 %6 offset:1632\n"
-                     "ds_write_addtid_b32 %7 offset:1904\n"
-                     "ds_write_addtid_b32 %8 offset:2176\n"
-                     "ds_write_addtid_b32 %9 offset:2448\n"
-                     "ds_write_addtid_b32 %10 offset:2720\n"
-                     :: "v"(acc.mx), "v"(acc.my), "v"(acc.mxx), "v"(acc.mxy), "v"(acc.myy), "v"(acc.dop), "v"(acc.prune),
-                        "v"(acc.split), "v"(acc.df0), "v"(acc.df1), "v"(acc.df2), "s"(red_base) : "memory");
-        gsr_wave_lds_fence();
-        const float4* rd = reinterpret_cast<const float4*>(red + rslot);
-        const float4 a = rd[0], b = rd[1], c = rd[2], d = rd[3];
-        gsr_wave_lds_fence();
-        const v2f t = (((v2f){a.x, a.y} + (v2f){a.z, a.w}) + ((v2f){b.x, b.y} + (v2f){b.z, b.w})) +
-                      (((v2f){c.x, c.y} + (v2f){c.z, c.w}) + ((v2f){d.x, d.y} + (v2f){d.z, d.w}));
-        float tot = t.x + t.y;
-        asm volatile("s_nop 1\n"
-                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 1\n"
-                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                     : "+v"(tot));
-        if (lane < 44 && (lane & 3) == 0) partial[(size_t)GSR_PARTIAL_FLOATS * inst_j + (lane >> 2)] = tot;
-      }
-      if (!more) break;
-    }
-  }
-}
 
 // Plans the frame, one thread per tile.  A tile longer than `seg_pairs` is cut into segments (the last one shorter),
 // numbered consecutively from a slot range the tile reserves with one integer atomic on the (zero-initialised) segment

@@ -30,7 +30,7 @@ from .controller_math import PointState, find_split_prune_indexes
 from .data_types import CameraParams, Gaussians3D, RasterConfig
 from .optim import ParameterClass, VisibilityAwareLaProp, point_basis_rows
 from .tensor_rows import TensorRows
-from .loss import clamped_mse_loss
+from .loss import clamped_mse_loss, reference_loss
 from .renderer import GradOut, render_gaussians
 
 PARAM_NAMES = ("position", "log_scaling", "rotation", "alpha_logit", "feature")
@@ -88,7 +88,8 @@ class MiniTrainer:
   def __init__(self, gaussians: Gaussians3D, cameras: Sequence[CameraParams], targets: Sequence[torch.Tensor],
                config: Optional[RasterConfig] = None, lr: float = 1e-3, densify_every: int = 25,
                target_points: Optional[int] = None, prune_rate: float = 0.025, min_views: int = 5,
-               max_scale_px: float = 200.0, total_steps: int = 100, seed: int = 0, optimizer=VisibilityAwareLaProp):
+               max_scale_px: float = 200.0, total_steps: int = 100, seed: int = 0, optimizer=VisibilityAwareLaProp,
+               loss: str = "mse"):
     self.config = config or RasterConfig(compute_visibility=True, compute_point_heuristic=True)
     self.cameras, self.targets = list(cameras), list(targets)
     self.device = gaussians.position.device
@@ -106,6 +107,9 @@ class MiniTrainer:
     self.state = PointState.new_zeros(self.num_points, self.device)
     self.step_idx = 0
     self.log = TrainLog()
+    if loss not in ("mse", "ref"):
+      raise ValueError("loss must be 'mse' (clamped MSE, SURVEY.md section 8d) or 'ref' (the reference's L1 + MSE + SSIM mix)")
+    self.loss_kind = loss
 
   @property
   def num_points(self) -> int:
@@ -166,7 +170,10 @@ class MiniTrainer:
         r = render_gaussians(self.scene(), cam, self.config, use_sh=True, grad_out=grad_out)
         if r.points.idx.shape[0] == 0:
           raise RuntimeError("No visible points")                     # trainer.py:507-509
-        loss = clamped_mse_loss(r.image, target) if fused else F.mse_loss(r.image.clamp(0, 1), target)
+        if self.loss_kind == "ref":
+          loss = reference_loss(r.image, target)                      # trainer.py:448-488: L1 + MSE + multi-scale SSIM
+        else:
+          loss = clamped_mse_loss(r.image, target) if fused else F.mse_loss(r.image.clamp(0, 1), target)
         loss.backward()
       with torch.no_grad():
         # point_state.py:34-50 (camera order) and mlp_scene.py:244 (visible[idx] += visibility) in one launch

@@ -179,6 +179,8 @@ class MiniTrainer:
         # point_state.py:34-50 (camera order) and mlp_scene.py:244 (visible[idx] += visibility) in one launch
         self.state.add_rendering(r, visible_sum=self.points.visible)
         total += loss.detach()
+    if grad_out is not None:
+      grad_out.finish_batch()               # (a buffer no backward pass reached would be zero-filled here; none with >= 1 camera)
     self.optimizer_step()
     self.step_idx += 1
     self.log.losses.append(float(total.item()) / len(self.cameras))

@@ -231,8 +231,13 @@ class RasterOutputs:
 # rounding of a boundary may decide the other way and move the pixel -- and the sums of every splat composited there -- by
 # one minimal contribution.  ``want_margins`` reports how close the fp64 walk came to each boundary IN UNITS OF WHAT ONE
 # fp32 ULP OF ROUNDING IN THE OPERANDS MOVES THE TESTED QUANTITY BY:
-#   q vs qlim   one ulp in the pixel offsets (coordinates of magnitude |pixel|), the conic terms and qlim:
-#               dq1 = eps32 (2 (|t_x| |x| + |t_y| |y|) + |A| dx^2 + 2 |B dx dy| + |C| dy^2 + qlim),  t = conic d
+#   q vs qlim   one ulp in the pixel offsets (coordinates of magnitude |pixel|) and in qlim, and the rounding an fp32 CONIC
+#               carries -- it is the inverse of the 2x2 screen covariance, so one ulp in the covariance's entries (relative
+#               to its larger eigenvalue) is kappa ulps in the conic's, kappa = lambda_max / lambda_min of the conic:
+#               dq1 = eps32 (2 (|t_x| |x| + |t_y| |y|) + kappa (|A| dx^2 + 2 |B dx dy| + |C| dy^2) + qlim),  t = conic d
+#               (kappa is 1.5-4 on the benchmark scenes and reaches thousands in the fuzz sweep's needles: before round 4's
+#               extended sweep the term had no kappa, and 6 gradient rows of 1600 random scenes -- all on splats with kappa
+#               of 575-2430 whose few visible pixels lie at the rim of their support -- sat 9-77 "ulps" from a boundary)
 #   T vs T_eps  a product of j + 1 rounded factors:  dT1 = eps32 (j + 2) T
 #   alpha_raw vs the clamp:  da1 = alpha_raw (eps32 + dq1 / 2)
 #   depth order of two list neighbours that both contribute: relative gap / eps32
@@ -308,7 +313,11 @@ def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None,
       near_live = T_excl >= config.transmittance_eps * (1.0 - 1e-3)
       tx, ty = (A * dx + Bc * dy).abs(), (Bc * dx + Cc * dy).abs()
       xs, ys = pix[:, :, None, 0].abs().clamp_min(1.0), pix[:, :, None, 1].abs().clamp_min(1.0)
-      dq1 = e32 * (2.0 * (tx * xs + ty * ys) + A.abs() * dx * dx + 2.0 * (Bc * dx * dy).abs() + Cc.abs() * dy * dy + qlim.abs())
+      half, det = 0.5 * (A + Cc), (A * Cc - Bc * Bc).clamp_min(1e-300)
+      l1 = half + (half * half - det).clamp_min(0).sqrt()
+      kappa = (l1 * l1 / det).clamp_min(1.0)                                # lambda_max / lambda_min of the conic
+      dq1 = e32 * (2.0 * (tx * xs + ty * ys) + kappa * (A.abs() * dx * dx + 2.0 * (Bc * dx * dy).abs() + Cc.abs() * dy * dy)
+                   + qlim.abs())
       m = torch.where(listed & near_live, (q - qlim).abs() / dq1.clamp_min(1e-300), inf)
       steps = torch.arange(q.shape[2], dtype=q.dtype, device=q.device)[None, None, :] + 2.0
       dT1 = e32 * steps * T_excl.clamp_min(config.transmittance_eps * 0.5)

@@ -118,3 +118,103 @@ def test_random_scene_with_many_large_splats(seed):
     live.append(k)
     clean_or_isolated_flip(f"fuzz large {seed}", k, hip[k], orc[k], 2e-4)
   compare_explained(f"fuzz large {seed} (explained)", hip, orc, 2e-4, keys=live)
+
+
+def blown_up(g, seed):
+  """A tenth of the scene's splats scaled 8-40x and made faint (the large-splat variant above)."""
+  gen = torch.Generator().manual_seed(seed)
+  n = g.position.shape[0]
+  pick = torch.randperm(n, generator=gen)[: max(2, n // 10)]
+  ls, al = g.log_scaling.clone(), g.alpha_logit.clone()
+  ls[pick] += 2.1 + 1.6 * torch.rand(pick.numel(), 1, generator=gen)
+  al[pick] = -2.5 + 1.5 * torch.rand(pick.numel(), 1, generator=gen)
+  return sta.Gaussians3D(g.position, g.rotation, ls, al, g.feature)
+
+
+def test_extended_sweep_on_request():
+  """One-off wide net, off by default: ``GSPLAT_FUZZ_EXTRA=n`` runs seeds 1000 .. 1000+n-1 (every fourth one with the
+  large-splat variant) under the same rules as the sweep above and reports every seed that breaks one instead of stopping
+  at the first.  The result of the round's run is kept in profiles/ (r04_fuzz_extended.txt)."""
+  import os
+  extra = int(os.environ.get("GSPLAT_FUZZ_EXTRA", "0"))
+  if extra <= 0:
+    pytest.skip("set GSPLAT_FUZZ_EXTRA=n to run n more random scenes")
+  broken, outside_share_size, flips, above = [], [], 0, 0
+  for seed in range(1000, 1000 + extra):
+    g, cam, cfg = random_case(seed)
+    if seed % 4 == 3:
+      g = blown_up(g, seed)
+    hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+    orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+    try:
+      assert len(set(hip["idx"].tolist()) ^ set(orc["idx"].tolist())) == 0, "visible sets differ"
+      live = []
+      flipped = False
+      for k in KEYS:
+        if orc[k].abs().max() == 0:
+          assert hip[k].abs().max() == 0, (seed, k)
+          continue
+        live.append(k)
+        try:                                # the share / size rule of the committed sweep: counted here, not fatal --
+          flipped |= clean_or_isolated_flip(f"fuzz x{seed}", k, hip[k], orc[k], 2e-4)
+        except AssertionError as e:         # an explained flip has no principled size bound (a splat seen through a dozen
+          flipped = True                    # rim pixels loses a tenth of its gradient row with one of them)
+          outside_share_size.append((seed, k, str(e)[-60:]))
+      above += compare_explained(f"fuzz x{seed} (explained)", hip, orc, 2e-4, keys=live, size=1.0)
+      flips += int(flipped)
+    except AssertionError as e:
+      broken.append((seed, str(e)[:300]))
+    if (seed - 999) % 20 == 0:
+      print(f"[extended sweep] {seed - 999} scenes, {flips} with a flip, {above} entries above tolerance, "
+            f"{len(broken)} broken", flush=True)
+  print(f"[extended sweep] seeds 1000..{999 + extra}: {flips} scenes with an isolated flip, {above} entries above "
+        f"2e-4, unexplained / broken: {broken}; explained but outside the committed sweep's share / size allowance: "
+        f"{outside_share_size}", flush=True)
+  assert not broken, broken
+
+
+def test_diagnose_seeds_on_request():
+  """``GSPLAT_FUZZ_DIAG=1240,1789`` prints, for every gradient / per-point row above 2e-4 in those scenes of the extended
+  sweep, what the explained-flip rule looks at: the splat's margin, its own margin, its conic's condition, the row's error."""
+  import os
+  from helpers import conic_condition
+  seeds = [int(s) for s in os.environ.get("GSPLAT_FUZZ_DIAG", "").split(",") if s.strip()]
+  if not seeds:
+    pytest.skip("set GSPLAT_FUZZ_DIAG=seed,seed,...")
+  for seed in seeds:
+    g, cam, cfg = random_case(seed)
+    if seed >= 1000 and seed % 4 == 3:
+      g = blown_up(g, seed)
+    hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+    orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+    o32 = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0, dtype=torch.float32)
+    idx = orc["idx"].cpu()
+    sm, om = orc["splat_margin"].double().cpu(), orc["splat_own_margin"].double().cpu()
+    cond = conic_condition(orc["g2d"].detach().cpu())
+    g2d = orc["g2d"].detach().cpu()
+    print(f"--- seed {seed}: {idx.numel()} visible, image {tuple(orc['image'].shape)}, aa={cfg.antialias}")
+    for k in KEYS:
+      a, b = hip[k].detach().double().cpu(), orc[k].detach().double().cpu()
+      scale = max(b.abs().max().item(), 1e-30)
+      if scale == 1e-30:
+        continue
+      bad = ((a - b).abs() / scale) > 2e-4
+      if not bad.any():
+        continue
+      if k in ("image", "final_T"):
+        pm = orc["pixel_margin"].double().cpu()
+        ys, xs = torch.nonzero(bad.reshape(pm.shape[0], pm.shape[1], -1).any(dim=2), as_tuple=True)
+        for y, x in zip(ys.tolist(), xs.tolist()):
+          print(f"  {k:14s} pixel ({x},{y}) margin {pm[y, x]:.3g} err {((a - b).abs().reshape(pm.shape[0], pm.shape[1], -1)[y, x].max() / scale):.3g}")
+        continue
+      rows = bad.reshape(bad.shape[0], -1).any(dim=1)
+      per_point = rows.shape[0] == sm.shape[0] and not k.startswith("d_")
+      vis_rows = torch.nonzero(rows if per_point else rows[idx]).flatten().tolist()
+      for r in vis_rows:
+        full = r if per_point else int(idx[r])
+        ar, br = a.reshape(a.shape[0], -1)[full], b.reshape(b.shape[0], -1)[full]
+        cr = o32[k].detach().double().cpu().reshape(a.shape[0], -1)[full]
+        print(f"  {k:14s} oracle-fp32 row err/rowmax {((cr - br).abs().max() / br.abs().max().clamp_min(1e-30)):.3g}")
+        print(f"  {k:14s} visible row {r:5d} margin {sm[r]:9.3g} own {om[r]:9.3g} cond {cond[r]:9.3g} "
+              f"row_err/rowmax {((ar - br).abs().max() / br.abs().max().clamp_min(1e-30)):.3g} err/tensormax {((ar - br).abs().max() / scale):.3g} "
+              f"opacity {g2d[r, 5]:.3g} uv ({g2d[r, 0]:.1f},{g2d[r, 1]:.1f}) conic ({g2d[r, 2]:.3g},{g2d[r, 3]:.3g},{g2d[r, 4]:.3g})")

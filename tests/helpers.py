@@ -277,12 +277,21 @@ def oracle_render_and_grads_chunked(g, cam, config, use_sh, target=0.5, dtype=to
               d_alpha_logit=al.grad, d_feature=feat.grad, prune_cost=prune, split_score=split, num_overlaps=overlaps)
 
 
-def hip_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, device="cuda", loss_scale=1.0):
+def hip_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=False, device="cuda", loss_scale=1.0,
+                         three_call=False):
+  """``three_call``: the reference's own sequence (mlp_scene.py:375-378 / transfer_sh.py:49) -- project_to_image,
+  evaluate_sh_at, render_projected -- instead of the one-call form."""
   import splat_trainer_amd as sta
   gd = sta.Gaussians3D(*(t.clone().to(device).requires_grad_(True) for t in
                          (g.position, g.rotation, g.log_scaling, g.alpha_logit, g.feature)))
   camd = cam.to(device)
-  r = sta.render_gaussians(gd, camd, config, use_sh=use_sh, render_median_depth=want_median)
+  if three_call:
+    assert use_sh
+    g2d, depth, idx = sta.project_to_image(gd, camd, config)
+    feats = sta.evaluate_sh_at(gd.feature, gd.position, idx, camd.camera_position)
+    r = sta.render_projected(idx, g2d, feats, depth, camd, config, render_median_depth=want_median)
+  else:
+    r = sta.render_gaussians(gd, camd, config, use_sh=use_sh, render_median_depth=want_median)
   loss = ((r.image.clamp(0, 1) - target) ** 2).mean() * loss_scale
   loss.backward()
   return dict(rendering=r, image=r.image.detach(), final_T=r.final_transmittance, visibility=r.points.visibility,

@@ -133,7 +133,8 @@ def blown_up(g, seed):
 
 def test_extended_sweep_on_request():
   """One-off wide net, off by default: ``GSPLAT_FUZZ_EXTRA=n`` runs seeds 1000 .. 1000+n-1 (every fourth one with the
-  large-splat variant) under the same rules as the sweep above and reports every seed that breaks one instead of stopping
+  large-splat variant; the frame's path -- default, forced segments, checkpointed backward, three-call form -- varies with
+  the seed) under the same rules as the sweep above and reports every seed that breaks one instead of stopping
   at the first.  The result of the round's run is kept in profiles/ (r04_fuzz_extended.txt)."""
   import os
   extra = int(os.environ.get("GSPLAT_FUZZ_EXTRA", "0"))
@@ -144,7 +145,16 @@ def test_extended_sweep_on_request():
     g, cam, cfg = random_case(seed)
     if seed % 4 == 3:
       g = blown_up(g, seed)
-    hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+    # the paths a frame can take, by seed: 0 / 4 the product's own choices; 1 lists cut into tiny segments forward AND backward
+    # (the heavy-tile passes); 2 the checkpointed backward walk only; 3 the reference's three-call sequence
+    form = (seed // 4) % 5
+    import dataclasses
+    if form == 1:
+      n = 1 + seed % 13
+      cfg = dataclasses.replace(cfg, segment_pairs=n, segment_min_pairs=n)
+    elif form == 2:
+      cfg = dataclasses.replace(cfg, segment_pairs=4 * (1 + seed % 7), segment_min_pairs=10 ** 9)
+    hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0, three_call=form == 3)
     orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
     try:
       assert len(set(hip["idx"].tolist()) ^ set(orc["idx"].tolist())) == 0, "visible sets differ"

@@ -231,23 +231,29 @@ class RasterOutputs:
 # rounding of a boundary may decide the other way and move the pixel -- and the sums of every splat composited there -- by
 # one minimal contribution.  ``want_margins`` reports how close the fp64 walk came to each boundary IN UNITS OF WHAT ONE
 # fp32 ULP OF ROUNDING IN THE OPERANDS MOVES THE TESTED QUANTITY BY:
-#   q vs qlim   one ulp in the pixel offsets (coordinates of magnitude |pixel|) and in qlim, and the rounding an fp32 CONIC
+#   q vs qlim   one ulp in the pixel offsets (coordinates of magnitude |pixel|, plus |pixel - principal point| when the caller
+#               names it: the mean is c + f x / z) and in qlim, and the rounding an fp32 CONIC
 #               carries -- it is the inverse of the 2x2 screen covariance, so one ulp in the covariance's entries (relative
 #               to its larger eigenvalue) is kappa ulps in the conic's, kappa = lambda_max / lambda_min of the conic:
 #               dq1 = eps32 (2 (|t_x| |x| + |t_y| |y|) + kappa (|A| dx^2 + 2 |B dx dy| + |C| dy^2) + qlim),  t = conic d
 #               (kappa is 1.5-4 on the benchmark scenes and reaches thousands in the fuzz sweep's needles: before round 4's
 #               extended sweep the term had no kappa, and 6 gradient rows of 1600 random scenes -- all on splats with kappa
 #               of 575-2430 whose few visible pixels lie at the rim of their support -- sat 9-77 "ulps" from a boundary)
-#   T vs T_eps  a product of j + 1 rounded factors:  dT1 = eps32 (j + 2) T
+#   T vs T_eps  a product of rounded factors 1 - alpha_i, i in front of the entry: each contributes 2 eps32 and, where the clamp
+#               is inactive, alpha_i / (1 - alpha_i) (eps32 + dq1_i / 2):  dT1 = T (eps32 + sum_i f_i)
+#               (until round 4's mid-size sweep: eps32 (j + 2) T, which understates T's rounding behind nearly opaque splats
+#               a hundredfold -- one scene of 130 showed a saturation flip at "30 ulps" that the oracle's own fp32 run makes too)
 #   alpha_raw vs the clamp:  da1 = alpha_raw (eps32 + dq1 / 2)
 #   depth order of two list neighbours that both contribute: relative gap / eps32
+#   (``loss_clamp`` = (lo, hi), the caller's: a channel of the composited pixel vs the bounds its loss clamps the image to --
+#    the clamp passes the channel's gradient only inside them; unit = the rounding of the sum, see the code)
 # so that a parity test can demand that every entry outside its tolerance sits within a STATED number of ulps of a boundary
 # (tests/helpers.py: compare_explained).
 MARGIN_EPS32 = 2.0 ** -23
 
 
 def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None, want_median=False,
-                     pix_valid=None, want_margins=False):
+                     pix_valid=None, want_margins=False, loss_clamp=None, principal=None):
   """idx (B,L) splat ids (padded), valid (B,L), pix (B,P,2) pixel centres, pix_valid (B,P) inside-image mask.
 
   Returns image (B,P,C), final_T (B,P), w (B,P,L) weights, plus -- when dL_dimage (B,P,C) is given --
@@ -313,14 +319,26 @@ def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None,
       near_live = T_excl >= config.transmittance_eps * (1.0 - 1e-3)
       tx, ty = (A * dx + Bc * dy).abs(), (Bc * dx + Cc * dy).abs()
       xs, ys = pix[:, :, None, 0].abs().clamp_min(1.0), pix[:, :, None, 1].abs().clamp_min(1.0)
+      if principal is not None:
+        # the mean's coordinate is a SUM, u = c_x + f_x x / z: next to the image's left / top border it is a small difference
+        # of two numbers of magnitude c_x, good to an ulp of THOSE (seen in the mid-size sweep: u = 4.3 off by 30 of its own ulps)
+        xs = xs + (pix[:, :, None, 0] - float(principal[0])).abs()
+        ys = ys + (pix[:, :, None, 1] - float(principal[1])).abs()
       half, det = 0.5 * (A + Cc), (A * Cc - Bc * Bc).clamp_min(1e-300)
       l1 = half + (half * half - det).clamp_min(0).sqrt()
       kappa = (l1 * l1 / det).clamp_min(1.0)                                # lambda_max / lambda_min of the conic
       dq1 = e32 * (2.0 * (tx * xs + ty * ys) + kappa * (A.abs() * dx * dx + 2.0 * (Bc * dx * dy).abs() + Cc.abs() * dy * dy)
                    + qlim.abs())
       m = torch.where(listed & near_live, (q - qlim).abs() / dq1.clamp_min(1e-300), inf)
-      steps = torch.arange(q.shape[2], dtype=q.dtype, device=q.device)[None, None, :] + 2.0
-      dT1 = e32 * steps * T_excl.clamp_min(config.transmittance_eps * 0.5)
+      # T in front of list position j is a product of rounded factors 1 - alpha_i: each carries the rounding of the
+      # subtraction and of the multiplication that folds it in (2 eps32) and -- where the clamp is inactive -- the rounding of
+      # alpha_i = opacity exp(-q_i / 2) itself (eps32 + dq1_i / 2 relative) MAGNIFIED by alpha_i / (1 - alpha_i): behind a
+      # stack of nearly opaque splats T is good to hundreds of ulps, not to (j + 2).  Entries that do not contribute are
+      # exact factors of one.
+      rel_alpha = e32 + 0.5 * dq1
+      fr = torch.where(alpha > 0, 2.0 * e32 + torch.where(a_raw > config.clamp_max_alpha, torch.zeros_like(q),
+                                                           alpha / one_m.clamp_min(1e-300) * rel_alpha), torch.zeros_like(q))
+      dT1 = (torch.cumsum(fr, dim=2) - fr + e32) * T_excl.clamp_min(config.transmittance_eps * 0.5)
       m = torch.minimum(m, torch.where(listed & inside, (T_excl - config.transmittance_eps).abs() / dT1, inf))
       da1 = a_raw * (e32 + 0.5 * dq1)
       m = torch.minimum(m, torch.where(listed & inside & live, (a_raw - config.clamp_max_alpha).abs() / da1.clamp_min(1e-300), inf))
@@ -332,6 +350,16 @@ def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None,
       m[:, :, 1:] = torch.minimum(m[:, :, 1:], mg)
       m[:, :, :-1] = torch.minimum(m[:, :, :-1], mg)
       mpx = m.min(dim=2).values                                           # (B, P)
+      if loss_clamp is not None:
+        # the CALLER's decision: a loss on image.clamp(lo, hi) passes a channel's gradient only inside [lo, hi], so a channel
+        # within rounding of a bound switches the gradient of everything composited on that pixel.  One unit = what the
+        # rounding counted above does to the sum: every term w_i c_i carries w's relative rounding (T's and alpha's) plus the
+        # rounding of the accumulation.
+        rel_w = dT1 / T_excl.clamp_min(1e-300) + da1 / a_raw.clamp_min(1e-300) + e32
+        dC1 = torch.einsum('bpl,blc->bpc', w.detach() * rel_w, f.detach().abs())
+        img = image.detach()
+        dist = torch.minimum((img - loss_clamp[0]).abs(), (img - loss_clamp[1]).abs())
+        mpx = torch.minimum(mpx, (dist / dC1.clamp_min(1e-300)).min(dim=2).values)
       # a splat is touched by a pixel's flip when it contributes there (everything behind the flipped splat moves with T)
       # or is itself the candidate (its own entry is the close one)
       sm = torch.minimum(torch.where(w > 0, mpx[:, :, None].expand_as(m), inf), m).min(dim=1).values   # (B, L)
@@ -344,7 +372,7 @@ def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None,
 def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image_size, config,
               dL_dimage: Optional[torch.Tensor] = None, want_median: bool = False,
               tile_batch: int = 64, tiles: Optional[torch.Tensor] = None, lists=None,
-              want_margins: bool = False) -> RasterOutputs:
+              want_margins: bool = False, loss_clamp=None, principal=None) -> RasterOutputs:
   """Tile-batched compositing of projected splats.  Differentiable wrt g2d and feats (autograd).
 
   ``dL_dimage`` (H,W,C): when given, also returns the per-point heuristics prune_cost / split_score
@@ -393,7 +421,8 @@ def rasterize(g2d: torch.Tensor, depth: torch.Tensor, feats: torch.Tensor, image
     pix = torch.stack([px.to(dtype) + 0.5, py.to(dtype) + 0.5], dim=-1)
     gB = gpad[py, px] if gpad is not None else None
     res = _composite_batch(g2d, feats, depth, idx, valid, pix, config, gB, want_median,
-                           pix_valid=(px < W) & (py < H), want_margins=want_margins)
+                           pix_valid=(px < W) & (py < H), want_margins=want_margins, loss_clamp=loss_clamp,
+                           principal=principal)
     img, fT, w, med, extra = res[:5]
     image_parts.append((py, px, img))
     with torch.no_grad():

@@ -88,9 +88,10 @@ def clean_or_isolated_flip(label: str, key: str, a: torch.Tensor, b: torch.Tenso
 # dozen pixels at the rim of its support, one of which decides the other way because the fp32 conic of a needle is only good
 # to kappa ulps -- flips, once the margin counts the conic's own rounding (the oracle's fp32 run, whose conic rounds
 # differently, is within 1e-4 of the fp64 one on the same rows).
-FLIP_ULPS = 4.0             # observed with the conditioning-aware margin (oracle: kappa in dq1): <= 2.32 over the suite (c2 image;
-                            # everything else <= 1.31) and <= 0.78 over the 1600 scenes of the extended sweep (profiles/r04_fuzz_extended.txt).
-                            # Before the margin knew about kappa the bound was 8 and six rows of that sweep sat at 9-77.
+FLIP_ULPS = 4.0             # observed with the margin model of profiles/r04_fuzz_extended.txt (conic conditioning, the mean's coordinate as
+                            # a sum, the caller's clamp, T behind opaque splats): <= 1.31 over the suite (fuzz seed 222; c2 <= 0.37),
+                            # <= 0.78 over 1600 small and <= 0.58 over 110 mid-size random scenes.  The first form (one ulp per operand)
+                            # needed 8 and left nine rows of those sweeps between 9 and 77.
 COND_GAIN = 1e-5            # = 84 eps32 per unit of condition number; observed 6.3e-6 (seed 46) and 3.1e-6 (seed 73) in round 4's first
                             # form of the margin; with kappa in the margin those rows are explained as flips and this class is empty
 EXPLAINED_LOG = []          # (label, key, entries above tol, unexplained, largest margin among the flips, share of units flagged,
@@ -212,7 +213,7 @@ def oracle_render_and_grads(g, cam, config, use_sh, target=0.5, want_median=Fals
   else:
     feats = feat.detach()[idx]
   heur = oracle.rasterize(g2d.detach(), depth.detach(), feats, cam.image_size, config, dL_dimage=image.grad,
-                          want_margins=True)
+                          want_margins=True, loss_clamp=(0.0, 1.0), principal=(float(proj[2]), float(proj[3])))
   return dict(pixel_margin=heur.pixel_margin, splat_margin=heur.splat_margin, splat_own_margin=heur.splat_own_margin,
               image=image.detach(), final_T=out.final_T, visibility=out.visibility, median=out.median_depth,
               g2d=g2d.detach(), d_g2d=g2d.grad, depth=depth.detach(), screen_scale=sscale, idx=idx, loss=loss.detach(),
@@ -260,7 +261,7 @@ def oracle_render_and_grads_chunked(g, cam, config, use_sh, target=0.5, dtype=to
     loss.backward()
     with torch.no_grad():
       heur = oracle.rasterize(g2d_d.detach(), depth.detach(), feats_d.detach(), cam.image_size, config, tiles=tiles,
-                              lists=lists, dL_dimage=img.grad, want_margins=True)
+                              lists=lists, dL_dimage=img.grad, want_margins=True, loss_clamp=(0.0, 1.0), principal=(float(proj[2]), float(proj[3])))
       pmargin = torch.minimum(pmargin, heur.pixel_margin)
       smargin = torch.minimum(smargin, heur.splat_margin)
       omargin = torch.minimum(omargin, heur.splat_own_margin)

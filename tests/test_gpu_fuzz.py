@@ -14,11 +14,17 @@ from helpers import clean_or_isolated_flip, compare_explained, hip_render_and_gr
 pytestmark = pytest.mark.gpu
 
 
-def random_case(seed):
+def random_case(seed, mid=False):
+  """``mid``: thousands to tens of thousands of splats on images of a few hundred pixels (lists of hundreds of pairs per
+  tile, several radix-sort blocks, segmented tiles under the product's own thresholds) instead of hundreds on a thumbnail."""
   gen = torch.Generator().manual_seed(seed)
   r = lambda *s: torch.rand(*s, generator=gen)
-  n = int(20 + r(1).item() * 600)
-  w, h = int(8 + r(1).item() * 150), int(8 + r(1).item() * 110)
+  if mid:
+    n = int(3000 + r(1).item() ** 2 * 37000)
+    w, h = int(90 + r(1).item() * 500), int(70 + r(1).item() * 400)
+  else:
+    n = int(20 + r(1).item() * 600)
+    w, h = int(8 + r(1).item() * 150), int(8 + r(1).item() * 110)
   fov = math.radians(40 + 50 * r(1).item())
   fx = fy = w / (2 * math.tan(fov / 2))
   z = 0.05 + 12 * r(n) ** 2                                   # some in front of the near plane
@@ -138,11 +144,12 @@ def test_extended_sweep_on_request():
   at the first.  The result of the round's run is kept in profiles/ (r04_fuzz_extended.txt)."""
   import os
   extra = int(os.environ.get("GSPLAT_FUZZ_EXTRA", "0"))
+  mid = os.environ.get("GSPLAT_FUZZ_MID", "0") == "1"       # the same sweep over mid-size scenes (seconds of oracle per scene)
   if extra <= 0:
     pytest.skip("set GSPLAT_FUZZ_EXTRA=n to run n more random scenes")
   broken, outside_share_size, flips, above = [], [], 0, 0
   for seed in range(1000, 1000 + extra):
-    g, cam, cfg = random_case(seed)
+    g, cam, cfg = random_case(seed, mid=mid)
     if seed % 4 == 3:
       g = blown_up(g, seed)
     # the paths a frame can take, by seed: 0 / 4 the product's own choices; 1 lists cut into tiny segments forward AND backward
@@ -174,7 +181,7 @@ def test_extended_sweep_on_request():
       flips += int(flipped)
     except AssertionError as e:
       broken.append((seed, str(e)[:300]))
-    if (seed - 999) % 20 == 0:
+    if (seed - 999) % (2 if mid else 20) == 0:
       print(f"[extended sweep] {seed - 999} scenes, {flips} with a flip, {above} entries above tolerance, "
             f"{len(broken)} broken", flush=True)
   print(f"[extended sweep] seeds 1000..{999 + extra}: {flips} scenes with an isolated flip, {above} entries above "
@@ -191,11 +198,19 @@ def test_diagnose_seeds_on_request():
   seeds = [int(s) for s in os.environ.get("GSPLAT_FUZZ_DIAG", "").split(",") if s.strip()]
   if not seeds:
     pytest.skip("set GSPLAT_FUZZ_DIAG=seed,seed,...")
+  mid = os.environ.get("GSPLAT_FUZZ_MID", "0") == "1"
   for seed in seeds:
-    g, cam, cfg = random_case(seed)
+    g, cam, cfg = random_case(seed, mid=mid)
     if seed >= 1000 and seed % 4 == 3:
       g = blown_up(g, seed)
-    hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
+    form = (seed // 4) % 5 if seed >= 1000 else 0              # (the extended sweep's choice of path)
+    import dataclasses
+    if form == 1:
+      cfg = dataclasses.replace(cfg, segment_pairs=1 + seed % 13, segment_min_pairs=1 + seed % 13)
+    elif form == 2:
+      cfg = dataclasses.replace(cfg, segment_pairs=4 * (1 + seed % 7), segment_min_pairs=10 ** 9)
+    print(f"--- seed {seed} form {form}")
+    hip = hip_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0, three_call=form == 3)
     orc = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0)
     o32 = oracle_render_and_grads(g, cam, cfg, use_sh=True, want_median=True, loss_scale=100.0, dtype=torch.float32)
     idx = orc["idx"].cpu()
@@ -215,7 +230,8 @@ def test_diagnose_seeds_on_request():
         pm = orc["pixel_margin"].double().cpu()
         ys, xs = torch.nonzero(bad.reshape(pm.shape[0], pm.shape[1], -1).any(dim=2), as_tuple=True)
         for y, x in zip(ys.tolist(), xs.tolist()):
-          print(f"  {k:14s} pixel ({x},{y}) margin {pm[y, x]:.3g} err {((a - b).abs().reshape(pm.shape[0], pm.shape[1], -1)[y, x].max() / scale):.3g}")
+          print(f"  {k:14s} pixel ({x},{y}) margin {pm[y, x]:.3g} err {((a - b).abs().reshape(pm.shape[0], pm.shape[1], -1)[y, x].max() / scale):.3g}"
+                f"  hip {a.reshape(pm.shape[0], pm.shape[1], -1)[y, x].tolist()} oracle {b.reshape(pm.shape[0], pm.shape[1], -1)[y, x].tolist()} tensor max {scale:.3g}")
         continue
       rows = bad.reshape(bad.shape[0], -1).any(dim=1)
       per_point = rows.shape[0] == sm.shape[0] and not k.startswith("d_")

@@ -305,7 +305,7 @@ def test_config3_full_size_sampled_tiles_match_oracle(n, w, h, ntiles, label):
     (((img.clamp(0, 1) - 0.5) ** 2) * cm[..., None]).sum().div(norm).mul(100.0).backward()
     with torch.no_grad():
       heur = oracle.rasterize(g2d_d.detach(), order_depth, feats_d.detach(), (w, h), CFG, tiles=chunk, lists=lists,
-                              dL_dimage=img.grad, want_margins=True)
+                              dL_dimage=img.grad, want_margins=True, loss_clamp=(0.0, 1.0), principal=(float(proj[2]), float(proj[3])))
       pmargin, smargin = torch.minimum(pmargin, heur.pixel_margin), torch.minimum(smargin, heur.splat_margin)
       omargin = torch.minimum(omargin, heur.splat_own_margin)
       img_o += out.image.detach() * cm[..., None]

@@ -95,3 +95,34 @@ def test_analytic_pixel_terms_match_autograd():
   mag = g2d.grad[:, :2].norm(dim=1)[order]
   assert (split.sum(1).reshape(-1) + 1e-9 >= mag - 1e-9).all()
   assert split.sum() > 0 and prune.sum() > 0
+
+
+def test_margins_know_the_boundaries_they_are_asked_about():
+  """Hand-built cases for the decision margins (want_margins): a pixel exactly on the rim of a support has margin ~0 there and
+  a large one elsewhere; a needle's rim margin shrinks by its conic's condition number; a channel sitting on the bound of the
+  caller's clamp is flagged only when ``loss_clamp`` says the loss clamps there."""
+  cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  dt = torch.float64
+  # one round splat centred on pixel centre (8.5, 8.5), sigma 2 px: conic 1/4; the pixel 6 px to the right sits exactly on q = 9
+  g2d = torch.tensor([[8.5, 8.5, 0.25, 0.0, 0.25, 0.8]], dtype=dt)
+  depth = torch.tensor([[1.0]], dtype=dt)
+  feats = torch.tensor([[0.3, 0.6, 0.9]], dtype=dt)
+  out = oracle.rasterize(g2d, depth, feats, (32, 16), cfg, want_margins=True)
+  assert out.pixel_margin[8, 14] < 1e-6                    # q == 9 == qlim exactly
+  assert out.pixel_margin[8, 8] > 1e4 and out.pixel_margin[8, 11] > 1e4
+  assert out.splat_own_margin[0] < 1e-6
+  # the same distance from the rim in q, round splat vs needle (condition 100): the conic part of the unit grows 100x
+  # (6.25 -> 625 of 49 -> 668 in all, with the offset and q_lim parts unchanged): the margin shrinks 13.6x
+  round_ = torch.tensor([[8.5, 8.5, 0.25, 0.0, 0.25, 0.8]], dtype=dt)
+  needle = torch.tensor([[8.5, 8.5, 0.25, 0.0, 0.0025, 0.8]], dtype=dt)
+  m_round = oracle.rasterize(round_, depth, feats, (32, 16), cfg, want_margins=True).pixel_margin[8, 13]    # dx = 5: q = 6.25
+  m_needle = oracle.rasterize(needle, depth, feats, (32, 16), cfg, want_margins=True).pixel_margin[8, 13]
+  assert 12 < m_round / m_needle < 15, (m_round, m_needle)
+  # a channel exactly on the clamp's upper bound at the centre pixel: alpha = opacity there, colour = 1 / opacity
+  feats1 = torch.tensor([[0.5, 1.0 / 0.8, 0.2]], dtype=dt)
+  plain = oracle.rasterize(round_, depth, feats1, (32, 16), cfg, want_margins=True)
+  clamped = oracle.rasterize(round_, depth, feats1, (32, 16), cfg, want_margins=True, loss_clamp=(0.0, 1.0))
+  assert plain.pixel_margin[8, 8] > 1e4 and clamped.pixel_margin[8, 8] < 4.0
+  assert clamped.splat_margin[0] < 4.0 and plain.image[8, 8, 1] == clamped.image[8, 8, 1]
+  # far from both bounds nothing changes
+  assert clamped.pixel_margin[8, 11] > 1e3

@@ -244,7 +244,8 @@ class RasterOutputs:
 #               (until round 4's mid-size sweep: eps32 (j + 2) T, which understates T's rounding behind nearly opaque splats
 #               a hundredfold -- one scene of 130 showed a saturation flip at "30 ulps" that the oracle's own fp32 run makes too)
 #   alpha_raw vs the clamp:  da1 = alpha_raw (eps32 + dq1 / 2)
-#   depth order of two list neighbours that both contribute: relative gap / eps32
+#   depth order of two list neighbours that could both contribute (inside their supports, the pixel alive at the first):
+#               relative gap / eps32
 #   (``loss_clamp`` = (lo, hi), the caller's: a channel of the composited pixel vs the bounds its loss clamps the image to --
 #    the clamp passes the channel's gradient only inside them; unit = the rounding of the sum, see the code)
 # so that a parity test can demand that every entry outside its tolerance sits within a STATED number of ulps of a boundary
@@ -345,7 +346,11 @@ def _composite_batch(g2d, feats, depth, idx, valid, pix, config, dL_dimage=None,
       # list neighbours that both contribute and whose depths an fp32 key cannot tell apart
       d = depth.reshape(-1)[idx]                                          # (B, L)
       gap = ((d[:, 1:] - d[:, :-1]).abs() / d[:, 1:].abs().clamp_min(1e-300)) / e32
-      both = (w[:, :, 1:] > 0) & (w[:, :, :-1] > 0)
+      # (both are CANDIDATES on a pixel still alive at the first of them -- not "both contribute": behind a nearly opaque
+      # first one the second is dead, and alive in the other order; seen in the held-out sweep, seed 3763: a saturated thumbnail
+      # whose two largest splats are 0.1 ulp apart in depth)
+      cand = listed & inside
+      both = cand[:, :, 1:] & cand[:, :, :-1] & near_live[:, :, :-1]
       mg = torch.where(both, gap[:, None, :].expand_as(both), inf[:, :, 1:])
       m[:, :, 1:] = torch.minimum(m[:, :, 1:], mg)
       m[:, :, :-1] = torch.minimum(m[:, :, :-1], mg)

@@ -126,3 +126,27 @@ def test_margins_know_the_boundaries_they_are_asked_about():
   assert clamped.splat_margin[0] < 4.0 and plain.image[8, 8, 1] == clamped.image[8, 8, 1]
   # far from both bounds nothing changes
   assert clamped.pixel_margin[8, 11] > 1e3
+
+
+def test_margins_charge_the_mean_as_a_sum_and_ties_to_every_candidate_pixel():
+  """(a) With the principal point named, a pixel next to the left border is charged the rounding of c_x, not of its own small
+  coordinate; (b) two splats 0.1 ulp apart in depth: every pixel inside both supports and alive at the first is within that of a
+  boundary -- also where the second one is dead behind the nearly opaque first."""
+  cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  dt = torch.float64
+  depth = torch.tensor([[1.0]], dtype=dt)
+  feats = torch.tensor([[0.3, 0.6, 0.9]], dtype=dt)
+  g2d = torch.tensor([[2.5, 8.5, 0.25, 0.0, 0.25, 0.8]], dtype=dt)          # centred on pixel (2, 8); (7, 8) has q = 6.25
+  plain = oracle.rasterize(g2d, depth, feats, (512, 16), cfg, want_margins=True).pixel_margin[8, 7]
+  named = oracle.rasterize(g2d, depth, feats, (512, 16), cfg, want_margins=True, principal=(256.0, 8.0)).pixel_margin[8, 7]
+  assert 5.0 < plain / named < 40.0, (plain, named)
+  # (b)
+  two = torch.tensor([[8.5, 8.5, 0.02, 0.0, 0.02, 0.99999], [9.5, 8.5, 0.02, 0.0, 0.02, 0.9]], dtype=dt)
+  depths = torch.tensor([[1.0], [1.0 + 0.1 * 2.0 ** -23]], dtype=dt)
+  f2 = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], dtype=dt)
+  cfg2 = RasterConfig(compute_visibility=True, compute_point_heuristic=True, clamp_max_alpha=0.99999)
+  out = oracle.rasterize(two, depths, f2, (24, 16), cfg2, want_margins=True)
+  assert out.final_T[8, 8] < cfg2.transmittance_eps                        # the first one saturates its centre pixel: the second is dead there
+  assert out.image[8, 8, 1] == 0
+  assert out.pixel_margin[8, 8] < 0.2 and out.pixel_margin[8, 12] < 0.2   # ... and both pixels are within the tie's 0.1 ulp
+  assert out.splat_own_margin.max() < 0.2

@@ -90,7 +90,7 @@ def clean_or_isolated_flip(label: str, key: str, a: torch.Tensor, b: torch.Tenso
 # differently, is within 1e-4 of the fp64 one on the same rows).
 FLIP_ULPS = 2.0             # (twice the modelled rounding) observed with the margin model of profiles/r04_fuzz_extended.txt (conic conditioning, the mean's coordinate as
                             # a sum, the caller's clamp, T behind opaque splats): <= 1.31 over the suite (fuzz seed 222; c2 <= 0.37),
-                            # <= 0.78 over 1600 small, <= 0.58 over 110 mid-size and <= 1.74 over 1600 held-out random scenes.  The first form (one ulp per operand)
+                            # <= 0.78 over 1600 small, <= 0.58 over 110 mid-size and <= 1.74 over 2444 held-out random scenes.  The first form (one ulp per operand)
                             # needed 8 and left nine rows of those sweeps between 9 and 77; with the
                             # conic and clamp terms alone the bound was 4 (c2 at 2.32 until the mean's coordinate was charged as a sum).
 COND_GAIN = 1e-5            # = 84 eps32 per unit of condition number; observed 6.3e-6 (seed 46) and 3.1e-6 (seed 73) in round 4's first
